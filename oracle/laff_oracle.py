@@ -1,0 +1,299 @@
+"""CPU oracle for the LAFF retrieval hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain numpy (fp32) restatement of the reference's arithmetic, written from the
+formulas, one function per reference symbol.  Only
+`tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may
+import this module, and only as the checker / the timed CPU baseline.  The
+product path (`laff_amd/`) never imports it and has no CPU fallback.
+
+Parity pinning: the reference ships no golden vectors or tests for this path
+(SURVEY.md section 4), so the oracle is pinned against fixtures produced by running the
+reference's own Python in the build container (`tools/gen_golden.py` ->
+`tests/golden/*.npz`); `tests/test_oracle_golden.py` checks every function here
+against them (max |diff| <= 2e-6 on unit-norm outputs, metrics exact).
+
+All citations are file:line under /root/reference.
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# loss.py / evaluation.py primitives
+# ------------------------------------------------------------------------------------------------
+def l2norm(X, eps=1e-13, axis=1):
+    """loss.l2norm (loss.py:8-13): X / (sqrt(sum X^2) + eps + 1e-14), fp32."""
+    X = _f32(X)
+    norm = np.sqrt(np.sum(X * X, axis=axis, keepdims=True, dtype=F32)).astype(F32)
+    norm = norm + F32(eps) + F32(1e-14)
+    return (X / norm).astype(F32)
+
+
+def cosine_sim(query, retrio):
+    """loss.cosine_sim (loss.py:30-34): re-normalise both operands, then mm."""
+    return (l2norm(query) @ l2norm(retrio).T).astype(F32)
+
+
+def np_l2norm(X):
+    """evaluation.l2norm (evaluation.py:11-16): X / (||X|| + 1e-10)."""
+    norm = np.linalg.norm(X, axis=1, keepdims=True)
+    return 1.0 * X / (norm + 1e-10)
+
+
+def np_cosine_sim(q, r):
+    """evaluation.cosine_sim (evaluation.py:44-49)."""
+    return np_l2norm(q).dot(np_l2norm(r).T)
+
+
+# ------------------------------------------------------------------------------------------------
+# a1 / a2: TransformNet (model/model.py:211-276) and the no-transform branch (:1801-1805, :1822-1823)
+# ------------------------------------------------------------------------------------------------
+def batch_norm_eval(y, bn, eps=1e-5):
+    """nn.BatchNorm1d in eval mode: (y - rm) / sqrt(rv + eps) * gamma + beta."""
+    gamma, beta, rm, rv = (_f32(t) for t in bn)
+    return ((y - rm) / np.sqrt(rv + F32(eps)) * gamma + beta).astype(F32)
+
+
+def activation(y, name):
+    if name in (None, False, '', 'none'):
+        return y
+    if name == 'tanh':
+        return np.tanh(y).astype(F32)
+    if name == 'relu':
+        return np.maximum(y, F32(0)).astype(F32)
+    if name == 'sigmoid':
+        return (F32(1) / (F32(1) + np.exp(-y))).astype(F32)
+    raise ValueError(name)
+
+
+def transform_net(x, W=None, b=None, act='tanh', bn=None, tile_heads=1):
+    """TransformNet.forward (model/model.py:257-276) in eval mode (dropout = identity).
+
+    fc -> activation -> BN.  `tile_heads` > 1 restates the caller-side `x.repeat(1, heads)`
+    of the no-transform branch (model/model.py:1822-1823, :1675-1676).
+    """
+    y = _f32(x)
+    if tile_heads > 1:
+        y = np.tile(y, (1, tile_heads))
+    if W is not None:
+        y = (y @ _f32(W).T).astype(F32)
+        if b is not None:
+            y = y + _f32(b)
+    y = activation(y, act)
+    if bn is not None:
+        y = batch_norm_eval(y, bn)
+    return _f32(y)
+
+
+# ------------------------------------------------------------------------------------------------
+# a6: Attention_1 (model/Attention.py:78-105)
+# ------------------------------------------------------------------------------------------------
+def attention_1(x, w, b, with_ave=False, mul=False, gw=1.0, return_weights=False):
+    """x (N, L, d) -> (N, d): softmax_L(c.w + b) weighted sum (+ gw * mean) then l2norm(eps=0)."""
+    x = _f32(x)
+    w = _f32(w).reshape(-1)
+    mean = x.mean(axis=1, dtype=F32)                         # raw_global_emb (:81)
+    c = x * mean[:, None, :] if mul else x                   # (:83-86)
+    logits = (c @ w).astype(F32) + F32(b)                    # (:88)
+    logits = logits - logits.max(axis=1, keepdims=True)
+    e = np.exp(logits).astype(F32)
+    a = (e / e.sum(axis=1, keepdims=True, dtype=F32)).astype(F32)   # (:89)
+    g = (a[:, :, None] * x)                                  # (:93)
+    if with_ave:
+        g = g + F32(gw) * mean[:, None, :]                   # (:94-99)
+    g = g.sum(axis=1, dtype=F32)                             # (:101)
+    out = l2norm(g, eps=0.0)                                 # (:103)
+    if return_weights:
+        return out, a
+    return out
+
+
+def just_average(x):
+    """JustAverage.forward (model/Attention.py:35-37)."""
+    return _f32(x).mean(axis=1, dtype=F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# a5: Multi_head_MyApply_Attention (model/Attention.py:508-531)
+# ------------------------------------------------------------------------------------------------
+def multi_head_attention(x, w, b, gw, H, with_ave=False, mul=False, split_head=True, l2norm_each_head=False):
+    """x (N, L, D) -> (N, H, d).  w (H, d), b (H,), gw (H,)."""
+    x = _f32(x)
+    N, L, D = x.shape
+    if split_head:
+        d = D // H
+        xh = x.reshape(N, L, H, d)                          # (:517)
+    else:
+        d = D
+        xh = np.repeat(x[:, :, None, :], H, axis=2)        # (:520)
+    if l2norm_each_head:
+        xh = l2norm(xh, axis=3)                             # (:522-523), default eps
+    outs = []
+    w = _f32(w).reshape(H, d)
+    for h in range(H):                                      # (:526-527)
+        outs.append(attention_1(xh[:, :, h, :], w[h], np.asarray(b).reshape(-1)[h], with_ave, mul,
+                                np.asarray(gw).reshape(-1)[h]))
+    return np.stack(outs, axis=1)                           # (:529)
+
+
+# ------------------------------------------------------------------------------------------------
+# towers: a3/a4 (model/model.py:1807-1876, :1663-1705) and a7 (:2147-2190)
+# ------------------------------------------------------------------------------------------------
+def fuse_tower(feature_specs, att, H):
+    """feature_specs: list of dicts for transform_net (x, W, b, act, bn, tile_heads), in stack order.
+    att: dict(w, b, gw, with_ave, mul, split_head, l2norm_each_head) or {'kind': 'just_average'}."""
+    planes = [transform_net(**s) for s in feature_specs]
+    local = np.stack(planes, axis=1)                        # torch.stack(dim=1) (:1862 / :1683)
+    if att.get('kind') == 'just_average':
+        return just_average(local)
+    if att.get('kind') == 'attention_1':
+        return attention_1(local, att['w'], att['b'], att['with_ave'], att['mul'], att['gw'])
+    return multi_head_attention(local, att['w'], att['b'], att['gw'], H, att['with_ave'], att['mul'],
+                                att.get('split_head', True), att.get('l2norm_each_head', False))
+
+
+def frame_attention(frames, w, b, with_ave=False, mul=False, gw=1.0, Wfc=None, bfc=None):
+    """Per-video Attention_1 over the F_max (zero padded) frames of the batch, exactly as the
+    reference runs it (model/model.py:2167-2173): the `[0:n]` slice there acts on the size-1 batch
+    axis, so every padded frame takes part; with `vis_frame_addFC` the Linear(512,512) is applied
+    to the padded zeros as well (:2134-2138).  frames (B, Fmax, 512) -> (B, 512)."""
+    frames = _f32(frames)
+    B = frames.shape[0]
+    out = np.empty((B, frames.shape[2]), F32)
+    for i in range(B):
+        x = frames[i:i + 1]
+        if Wfc is not None:
+            x = (x @ _f32(Wfc).T + _f32(bfc)).astype(F32)
+        out[i] = attention_1(x, w, b, with_ave, mul, gw)[0]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# a9-a11: similarity
+# ------------------------------------------------------------------------------------------------
+def txt2vis_matrix(txt_embs, vis_embs):
+    """W2VVPP.get_txt2vis_matrix (model/model.py:1003-1016): 2-D -> cosine_sim; 3-D -> mean over heads."""
+    t, v = _f32(txt_embs), _f32(vis_embs)
+    if t.ndim == 2:
+        return cosine_sim(t, v)
+    sims = [cosine_sim(t[:, h, :], v[:, h, :]) for h in range(v.shape[1])]
+    return np.mean(np.stack(sims, axis=0), axis=0, dtype=F32).astype(F32)
+
+
+def txt2vis_matrix_fast(txt_embs, vis_embs):
+    """Same value (to fp32 rounding) as one GEMM over the concatenated heads / H;
+    valid when rows are already unit-norm per head, which the towers guarantee."""
+    t, v = _f32(txt_embs), _f32(vis_embs)
+    if t.ndim == 2:
+        return (t @ v.T).astype(F32)
+    H = t.shape[1]
+    return ((t.reshape(t.shape[0], -1) @ v.reshape(v.shape[0], -1).T) / F32(H)).astype(F32)
+
+
+def predict_blocked(txt_emb_batches, vis_emb_batches, Nt, Nv):
+    """Loop B/C of W2VVPP.predict (model/model.py:1057-1077) on pre-computed embedding batches:
+    (idxs_rows, emb) pairs; per (text block, video block) get_txt2vis_matrix, scatter into scores."""
+    scores = np.zeros((Nt, Nv), F32)
+    for rows, te in txt_emb_batches:
+        for cols, ve in vis_emb_batches:
+            scores[np.ix_(rows, cols)] = txt2vis_matrix(te, ve)
+    return scores
+
+
+# ------------------------------------------------------------------------------------------------
+# a12-a14: ranks and metrics
+# ------------------------------------------------------------------------------------------------
+def gt_positions(score_row, gt_cols):
+    """1-based positions of the GT columns in the descending order of one score row -- what
+    `np.where(label_matrix[i] == 1)[0] + 1` yields after predictor.py:239-243.  Count-based so that it does not
+    depend on argsort's tie order: pos = 1 + #{c != g : s_c > s_g} (+ GT's own rank among GTs)."""
+    s = np.asarray(score_row)
+    gt_cols = np.asarray(gt_cols)
+    sg = np.sort(s[gt_cols])[::-1]
+    pos = []
+    for i, val in enumerate(sg):
+        pos.append(int(np.sum(s > val)) + 1 + (i - int(np.sum(sg[:i] > val))))
+    return np.array(sorted(pos))
+
+
+def eval_from_positions(positions):
+    """evaluation.eval (evaluation.py:92-109) given per-row sorted 1-based GT positions."""
+    ranks = np.array([p[0] for p in positions], dtype=np.float64)
+    aps = np.array([np.mean([(i + 1.) / p[i] for i in range(len(p))]) for p in positions])
+    r1, r5, r10 = [100.0 * np.mean(ranks <= k) for k in (1, 5, 10)]
+    medr = np.floor(np.median(ranks))
+    return (r1, r5, r10, medr, ranks.mean(), (1.0 / ranks).mean(), aps.mean())
+
+
+def eval_label_matrix(label_matrix):
+    """evaluation.eval (evaluation.py:92-109) on a 0/1 label matrix."""
+    lab = np.asarray(label_matrix).astype(int)
+    return eval_from_positions([np.where(row == 1)[0] + 1 for row in lab])
+
+
+def predictor_metrics(scores, txt_ids, vis_ids):
+    """predictor.py:232-246 (T2V) and :262-270 (V2T): id matching on `txt_id.split('#')[0]`."""
+    vis_index = {v: i for i, v in enumerate(vis_ids)}
+    owner = np.array([vis_index[t.split('#')[0]] for t in txt_ids])
+    t2v = eval_from_positions([gt_positions(scores[i], [owner[i]]) for i in range(scores.shape[0])])
+    v2t_pos = []
+    for v in range(scores.shape[1]):
+        v2t_pos.append(gt_positions(scores[:, v], np.where(owner == v)[0]))
+    v2t = eval_from_positions(v2t_pos)
+    return t2v, v2t
+
+
+def eval_qry2retro(sim, n_qry=1):
+    """evaluation.eval_qry2retro (evaluation.py:64-89): 0-based ranks, medr = floor(median)+1."""
+    sim = np.asarray(sim)
+    assert sim.shape[0] / sim.shape[1] == n_qry
+    ranks = np.zeros(sim.shape[0])
+    for i in range(sim.shape[0]):
+        g = int(i / n_qry) if n_qry == 1 else None
+        if g is None or i / n_qry != g:
+            raise ValueError('only meaningful for n_qry == 1 (true division in the reference)')
+        ranks[i] = np.sum(sim[i] > sim[i, g])
+    r1 = 100.0 * np.sum(ranks < 1) / len(ranks)
+    r5 = 100.0 * np.sum(ranks < 5) / len(ranks)
+    r10 = 100.0 * np.sum(ranks < 10) / len(ranks)
+    return (r1, r5, r10, np.floor(np.median(ranks)) + 1, ranks.mean() + 1, (1.0 / (ranks + 1)).mean())
+
+
+# ------------------------------------------------------------------------------------------------
+# state_dict -> specs (key names of SURVEY Appendix C)
+# ------------------------------------------------------------------------------------------------
+def _bn_from_sd(sd, prefix):
+    if prefix + 'bn1.weight' not in sd:
+        return None
+    return (sd[prefix + 'bn1.weight'], sd[prefix + 'bn1.bias'], sd[prefix + 'bn1.running_mean'],
+            sd[prefix + 'bn1.running_var'])
+
+
+def feature_spec(sd, prefix, x, act, H, no_transform):
+    bn = _bn_from_sd(sd, prefix)
+    if no_transform:
+        return dict(x=x, W=None, b=None, act=None, bn=bn, tile_heads=H)
+    return dict(x=x, W=sd[prefix + 'fc1.weight'], b=sd[prefix + 'fc1.bias'], act=act, bn=bn, tile_heads=1)
+
+
+def attention_from_sd(sd, prefix, H, with_ave, mul, split_head=True, l2norm_each_head=False):
+    w = np.stack([sd['%sattention_layer.%d.embedding_common.0.weight' % (prefix, h)].reshape(-1) for h in range(H)])
+    b = np.array([sd['%sattention_layer.%d.embedding_common.0.bias' % (prefix, h)].reshape(()) for h in range(H)], F32)
+    gw = np.array([sd['%sattention_layer.%d.global_emb_weight_net.weight' % (prefix, h)].reshape(())
+                   for h in range(H)], F32)
+    return dict(w=w, b=b, gw=gw, with_ave=with_ave, mul=mul, split_head=split_head,
+                l2norm_each_head=l2norm_each_head)
+
+
+FRAME_ATTENTION_FLAGS = {  # model/model.py:94-97 (name -> with_ave, mul)
+    'attention_noAverageMul_Ave': (True, False),
+    'attention_noAveNoAverageMul': (False, False),
+    'attention_averageMul': (True, True),
+    'average_AverageMul_noAve': (False, True),
+}
+
