@@ -1,0 +1,145 @@
+/*
+ * laff_hip.h -- C ABI of liblaff_hip.so: the MI355X (gfx950) kernels behind the LAFF retrieval hot path.
+ *
+ * The reference (ruc-aimc-lab/LAFF, pure Python/PyTorch) has no FFI layer; its boundary is the nn.Module
+ * API in model/model.py.  laff_amd/ keeps that Python surface and calls the entry points below through
+ * ctypes.  Each entry point names the reference code it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - every pointer is CALLER-OWNED DEVICE MEMORY (hipMalloc / a torch tensor's data_ptr) unless the
+ *     parameter is documented as host memory; the library neither frees nor retains it past the call;
+ *   - all matrices are row-major fp32 unless stated; `ld*` = leading dimension in ELEMENTS;
+ *   - calls are asynchronous and ordered on the stream bound to the ctx (laff_ctx_set_stream);
+ *     only laff_rank_metrics / laff_device_info synchronise;
+ *   - return value: 0 = LAFF_OK, negative = error; laff_last_error() returns the thread-local message;
+ *   - a ctx is not thread-safe; distinct ctxs are independent.  No exceptions cross this boundary.
+ */
+#ifndef LAFF_HIP_H
+#define LAFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAFF_ABI_VERSION 1
+
+enum {
+    LAFF_OK = 0,
+    LAFF_E_ARG = -1,          /* null pointer / negative size / bad enum */
+    LAFF_E_SHAPE = -2,        /* shape outside what the kernels support (message says which) */
+    LAFF_E_ALIGN = -3,        /* pointer / leading dimension alignment */
+    LAFF_E_HIP = -4,          /* a HIP runtime call failed (message carries hipGetErrorString) */
+    LAFF_E_UNSUPPORTED = -5
+};
+
+/* activation of TransformNet (model/model.py:236-243) */
+enum { LAFF_ACT_NONE = 0, LAFF_ACT_TANH = 1, LAFF_ACT_RELU = 2, LAFF_ACT_SIGMOID = 3 };
+
+/* flags of the attention kernels (Attention_1 ctor, model/Attention.py:48-63; Multi_head ctor :489-506) */
+enum {
+    LAFF_ATT_WITH_AVE = 1,          /* g += gw * mean_L(x)           (Attention.py:94-99) */
+    LAFF_ATT_MUL = 2,               /* logits on x * mean_L(x)       (Attention.py:83-86) */
+    LAFF_ATT_L2NORM_EACH_HEAD = 4,  /* l2norm(x, dim=3) per head     (Attention.py:522-523) */
+    LAFF_ATT_NO_SPLIT_HEAD = 8,     /* every head sees all D columns (Attention.py:520)   */
+    LAFF_ATT_JUST_AVERAGE = 16      /* JustAverage: mean over L, no softmax, no norm (Attention.py:35-37) */
+};
+
+/* operand precision of the similarity GEMM */
+enum {
+    LAFF_PREC_FP32 = 0,    /* fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an fp32 fma chain          */
+    LAFF_PREC_FP16 = 1,    /* one fp16 MFMA pass: max |d cos| ~ 7e-5 at d=512 (inside the 1e-4 contract) */
+    LAFF_PREC_BF16 = 2,    /* one bf16 MFMA pass: ~5e-4 -- for rank-identity workloads only              */
+    LAFF_PREC_FP16X3 = 3,  /* fp16 hi+lo split, 3 MFMA passes: ~1e-7                                    */
+    LAFF_PREC_BF16X3 = 4   /* bf16 hi+lo split, 3 MFMA passes: ~1e-6                                    */
+};
+
+typedef struct laff_ctx laff_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int laff_abi_version(void);
+const char* laff_last_error(void);
+/* device: HIP ordinal; hip_stream: hipStream_t (NULL = default stream). */
+int laff_ctx_create(int device, void* hip_stream, laff_ctx** out);
+int laff_ctx_set_stream(laff_ctx* ctx, void* hip_stream);
+int laff_ctx_destroy(laff_ctx* ctx);
+/* host out: [0]=CU count, [1]=clock MHz, [2]=LDS bytes per CU-workgroup limit, [3]=wavefront size */
+int laff_device_info(laff_ctx* ctx, int out[4]);
+
+/* ---- a1: TransformNet.forward (model/model.py:257-276), eval mode ------------------------------------
+ * Y[N,D] = (act(X[N,Dk] . W[D,Dk]^T + bias)) * bn_scale + bn_shift
+ * bias / bn_scale / bn_shift may be NULL (absent stage).  bn_* are the folded eval-mode BatchNorm1d:
+ * scale = gamma / sqrt(running_var + 1e-5), shift = beta - running_mean * scale.
+ * fp32 MFMA; any N, Dk, D >= 1 (16-byte aligned rows take the direct-to-LDS path). */
+int laff_fc_act_bn(laff_ctx* ctx, const float* X, int N, int Dk, int ldx, const float* W, int ldw,
+                   const float* bias, const float* bn_scale, const float* bn_shift, int D, int act,
+                   float* Y, int ldy);
+
+/* ---- a2-a6: stack + Multi_head_MyApply_Attention / Attention_1 / JustAverage ----------------------------
+ * (model/model.py:1858-1876, :1663-1705; model/Attention.py:508-531, :78-105)
+ * One feature plane per fused feature; nothing is stacked or tiled in memory.
+ *   x_l[n, h, c] = src_l[n, (tile ? c : h*d + c)] * scale_l[h*d + c] + shift_l[h*d + c]
+ * tile != 0 restates the no-transform branch `x.repeat(1, heads)` + BatchNorm1d(D)
+ * (model/model.py:1801-1805, 1822-1823; text side :659-664, 1675-1676): src has d columns. */
+typedef struct {
+    const float* src;     /* [N, ld] */
+    int ld;
+    int tile;
+    const float* scale;   /* [H*d] or NULL (=1) */
+    const float* shift;   /* [H*d] or NULL (=0) */
+} laff_plane;
+
+/* E[N,H,d] (unit L2 norm per (n,h) unless JUST_AVERAGE).  w [H,d], b [H], gw [H] device arrays.
+ * attn_w: optional [N,H,L] softmax weights (the `self.weights` side output, Attention.py:90).
+ * L <= 8, d % 4 == 0.  With NO_SPLIT_HEAD every head reads columns [0,d) (d = D). */
+int laff_fuse(laff_ctx* ctx, const laff_plane* planes /*host array of L*/, int L, int N, int H, int d,
+              const float* w, const float* b, const float* gw, unsigned flags, float* E, float* attn_w);
+
+/* ---- a7: per-video frame attention of VisMutiTransformNetPlusFrameFeat (model/model.py:2163-2173) --------
+ * V[B,d] = Attention_1 over the Fmax frames of each video; frames[B,Fmax,d] zero padded.
+ * lens != NULL: frames >= lens[b] are known zeros and are accounted for analytically (they still take
+ * part in the softmax and in mean_L exactly as in the reference, whose mask slice is a no-op);
+ * lens == NULL: all Fmax frames are read (needed behind vis_frame_addFC, where padding becomes the bias). */
+int laff_frame_fuse(laff_ctx* ctx, const float* frames, const int* lens, int B, int Fmax, int d,
+                    const float* w /*[d]*/, const float* b /*[1]*/, const float* gw /*[1]*/, unsigned flags,
+                    float* V);
+
+/* ---- a8: loss.l2norm (loss.py:8-13) + operand packing for the similarity GEMM ---------------------------
+ * For each (n,h): y = x / (||x||_2 + eps + 1e-14) if normalize, then y * prescale, converted to `precision`.
+ * out layout: FP32 -> float [N, H*d]; FP16/BF16 -> 16-bit [N, H*d]; *X3 -> two planes [2][N, H*d] (hi, lo).
+ * laff_packed_bytes gives the size. */
+int laff_packed_bytes(int N, int K, int precision, size_t* out);
+int laff_pack_rows(laff_ctx* ctx, const float* E, int N, int H, int d, int lde, int normalize, float eps,
+                   float prescale, int precision, void* out);
+
+/* ---- a9-a11: loss.cosine_sim + W2VVPP.get_txt2vis_matrix (loss.py:30-34, model/model.py:1003-1016) ------
+ * S[Nt,Nv] = scale * T[Nt,K] . V[Nv,K]^T on operands produced by laff_pack_rows (K = H*d, scale = 1/(H*prescale^2)).
+ * S may be NULL when only ranks are wanted.  If gt_col != NULL the epilogue also accumulates
+ *   count[t] += #{ v : v + col0 != gt_col[t] and S[t,v] > s_gt[t] }   (count must be zeroed by the caller)
+ * which is the argsort/label loop of predictor.py:232-244 in count form.  K % 64 == 0 (16-bit), K % 32 == 0 (fp32). */
+int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale,
+                  int precision, float* S, int lds, const int* gt_col, int col0, const float* s_gt,
+                  int* count);
+
+/* s_gt[t] = S[t, gt_col[t]-col0] if that column is in [0,Nv) else -inf  (shard-local ground-truth score) */
+int laff_gather_gt(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0,
+                   float* s_gt);
+/* count[t] (+)= #{ v in [0,Nv) : v + col0 != gt_col[t] and S[t,v] > s_gt[t] }; accumulate != 0 adds. */
+int laff_rank_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0,
+                    const float* s_gt, int* count, int accumulate);
+/* Video-to-text direction (predictor.py:262-270): for every text t with owner video gt_col[t]:
+ *   count[t] = #{ t' != t : S[t', v] > S[t, v] },  v = gt_col[t] - col0 in [0,Nv)  (others untouched).
+ * grp_off[Nv+1] / grp_idx[Nt]: CSR of texts grouped by owner column (local). */
+int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* grp_off,
+                   const int* grp_idx, int max_group, int* count);
+
+/* ---- a13: evaluation.eval (evaluation.py:92-109) for single-GT rows ---------------------------------------
+ * rank1[Nq] device int32, 1-based.  out7 (host) = r1, r5, r10, medr, meanr, mir, mAP.  Synchronises the stream. */
+int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, double out7[7]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAFF_HIP_H */

@@ -1,0 +1,61 @@
+"""ctypes binding of liblaff_hip.so (include/laff_hip.h).  No fallback: a missing library is an error."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'liblaff_hip.so')
+
+# enums of include/laff_hip.h
+ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
+ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
+PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
+ABI_VERSION = 1
+
+
+class Plane(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('ld', C.c_int), ('tile', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p)]
+
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+SIGNATURES = {
+    'laff_abi_version': (C.c_int, []),
+    'laff_last_error': (C.c_char_p, []),
+    'laff_ctx_create': (C.c_int, [_I, _P, C.POINTER(_P)]),
+    'laff_ctx_set_stream': (C.c_int, [_P, _P]),
+    'laff_ctx_destroy': (C.c_int, [_P]),
+    'laff_device_info': (C.c_int, [_P, C.POINTER(_I)]),
+    'laff_fc_act_bn': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I]),
+    'laff_fuse': (C.c_int, [_P, C.POINTER(Plane), _I, _I, _I, _I, _P, _P, _P, C.c_uint, _P, _P]),
+    'laff_frame_fuse': (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, C.c_uint, _P]),
+    'laff_packed_bytes': (C.c_int, [_I, _I, _I, C.POINTER(C.c_size_t)]),
+    'laff_pack_rows': (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
+    'laff_sim_gemm': (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P]),
+    'laff_gather_gt': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P]),
+    'laff_rank_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I]),
+    'laff_v2t_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    'laff_rank_metrics': (C.c_int, [_P, _P, _I, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raises if it has not been built (python -m laff_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('liblaff_hip.so is missing (%s): build it with `python -m laff_amd.build`; '
+                               'laff_amd has no CPU fallback' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if lib.laff_abi_version() != ABI_VERSION:
+            raise RuntimeError('liblaff_hip.so ABI %d != binding ABI %d: rebuild' % (lib.laff_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError('liblaff_hip: %s (rc=%d)' % (load().laff_last_error().decode(), rc))

@@ -1,0 +1,294 @@
+// api.hip -- extern "C" surface of liblaff_hip.so (see include/laff_hip.h for the contract).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+struct laff_ctx {
+    int device;
+    hipStream_t stream;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(LAFF_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define CHECK_CTX(ctx) \
+    if (!(ctx)) return fail(LAFF_E_ARG, "%s: null ctx", __func__)
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+bool is_x3(int p) { return p == LAFF_PREC_FP16X3 || p == LAFF_PREC_BF16X3; }
+int elem_size(int p) { return p == LAFF_PREC_FP32 ? 4 : 2; }
+
+}  // namespace
+
+extern "C" {
+
+int laff_abi_version(void) { return LAFF_ABI_VERSION; }
+
+const char* laff_last_error(void) { return g_err.c_str(); }
+
+int laff_ctx_create(int device, void* hip_stream, laff_ctx** out) {
+    if (!out) return fail(LAFF_E_ARG, "laff_ctx_create: null out");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(LAFF_E_ARG, "laff_ctx_create: device %d out of range (%d devices)", device, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LAFF_E_UNSUPPORTED, "laff_ctx_create: device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    laff_ctx* c = new laff_ctx();
+    c->device = device;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    *out = c;
+    return LAFF_OK;
+}
+
+int laff_ctx_set_stream(laff_ctx* ctx, void* hip_stream) {
+    CHECK_CTX(ctx);
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return LAFF_OK;
+}
+
+int laff_ctx_destroy(laff_ctx* ctx) {
+    delete ctx;
+    return LAFF_OK;
+}
+
+int laff_device_info(laff_ctx* ctx, int out[4]) {
+    CHECK_CTX(ctx);
+    if (!out) return fail(LAFF_E_ARG, "laff_device_info: null out");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    out[0] = prop.multiProcessorCount;
+    out[1] = prop.clockRate / 1000;
+    out[2] = (int)prop.sharedMemPerBlock;
+    out[3] = prop.warpSize;
+    return LAFF_OK;
+}
+
+int laff_fc_act_bn(laff_ctx* ctx, const float* X, int N, int Dk, int ldx, const float* W, int ldw, const float* bias,
+                   const float* bn_scale, const float* bn_shift, int D, int act, float* Y, int ldy) {
+    CHECK_CTX(ctx);
+    if (!X || !W || !Y) return fail(LAFF_E_ARG, "laff_fc_act_bn: null X/W/Y");
+    if (N < 0 || Dk < 1 || D < 1 || ldx < Dk || ldw < Dk || ldy < D)
+        return fail(LAFF_E_SHAPE, "laff_fc_act_bn: bad shape N=%d Dk=%d D=%d ldx=%d ldw=%d ldy=%d", N, Dk, D, ldx, ldw, ldy);
+    if (act < LAFF_ACT_NONE || act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fc_act_bn: bad act %d", act);
+    if ((bn_scale == nullptr) != (bn_shift == nullptr)) return fail(LAFF_E_ARG, "laff_fc_act_bn: bn_scale/bn_shift must come together");
+    if (N == 0) return LAFF_OK;
+    DeviceGuard g(ctx->device);
+    laff::GemmArgs a{};
+    a.R = X; a.C = W; a.nR = N; a.nC = D; a.K = Dk; a.ldR = ldx; a.ldC = ldw;
+    a.nseg = 1; a.segR[0] = a.segC[0] = 0;
+    a.out = Y; a.ldo = ldy; a.scale = 1.0f;
+    a.bias = bias; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.act = act;
+    const bool glds = aligned16(X) && aligned16(W) && (ldx % 4 == 0) && (ldw % 4 == 0) && (Dk % 4 == 0);
+    HIP_TRY(laff::launch_gemm_nt(a, laff::GEMM_F32, glds, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_fuse(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
+              const float* gw, unsigned flags, float* E, float* attn_w) {
+    CHECK_CTX(ctx);
+    if (!planes || !E) return fail(LAFF_E_ARG, "laff_fuse: null planes/E");
+    if (L < 1 || L > laff::MAX_L) return fail(LAFF_E_SHAPE, "laff_fuse: L=%d outside [1,%d]", L, laff::MAX_L);
+    if (N < 0 || H < 1 || d < 4 || (d & 3)) return fail(LAFF_E_SHAPE, "laff_fuse: need N>=0, H>=1, d%%4==0 (N=%d H=%d d=%d)", N, H, d);
+    const bool javg = flags & LAFF_ATT_JUST_AVERAGE;
+    if (!javg && (!w || !b)) return fail(LAFF_E_ARG, "laff_fuse: null w/b");
+    if ((flags & LAFF_ATT_WITH_AVE) && !gw) return fail(LAFF_E_ARG, "laff_fuse: WITH_AVE needs gw");
+    if (!aligned16(E) || (w && !aligned16(w))) return fail(LAFF_E_ALIGN, "laff_fuse: E/w must be 16-byte aligned");
+    const bool nosplit = flags & LAFF_ATT_NO_SPLIT_HEAD;
+    laff::FuseArgs a{};
+    for (int l = 0; l < L; ++l) {
+        const laff_plane& p = planes[l];
+        if (!p.src) return fail(LAFF_E_ARG, "laff_fuse: plane %d has null src", l);
+        if ((p.scale == nullptr) != (p.shift == nullptr)) return fail(LAFF_E_ARG, "laff_fuse: plane %d scale/shift must come together", l);
+        if (p.tile && nosplit) return fail(LAFF_E_UNSUPPORTED, "laff_fuse: tiled plane with NO_SPLIT_HEAD");
+        const int need = p.tile ? d : (nosplit ? d : H * d);
+        if (p.ld < need || (p.ld & 3)) return fail(LAFF_E_SHAPE, "laff_fuse: plane %d ld=%d (need >= %d, multiple of 4)", l, p.ld, need);
+        if (!aligned16(p.src) || (p.scale && (!aligned16(p.scale) || !aligned16(p.shift))))
+            return fail(LAFF_E_ALIGN, "laff_fuse: plane %d not 16-byte aligned", l);
+        a.src[l] = p.src; a.ld[l] = p.ld; a.tile[l] = p.tile; a.scale[l] = p.scale; a.shift[l] = p.shift;
+    }
+    if (N == 0) return LAFF_OK;
+    a.L = L; a.N = N; a.H = H; a.d = d; a.head_stride = nosplit ? 0 : d;
+    a.w = w; a.b = b; a.gw = gw; a.flags = flags; a.E = E; a.attn_w = attn_w;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_fuse(a, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_frame_fuse(laff_ctx* ctx, const float* frames, const int* lens, int B, int Fmax, int d, const float* w,
+                    const float* b, const float* gw, unsigned flags, float* V) {
+    CHECK_CTX(ctx);
+    if (!frames || !w || !b || !V) return fail(LAFF_E_ARG, "laff_frame_fuse: null frames/w/b/V");
+    if (B < 0 || Fmax < 1 || d < 4 || (d & 3) || d > 1024)
+        return fail(LAFF_E_SHAPE, "laff_frame_fuse: need B>=0, Fmax>=1, d%%4==0, d<=1024 (B=%d Fmax=%d d=%d)", B, Fmax, d);
+    if ((flags & LAFF_ATT_WITH_AVE) && !gw) return fail(LAFF_E_ARG, "laff_frame_fuse: WITH_AVE needs gw");
+    if (flags & ~(unsigned)(LAFF_ATT_WITH_AVE | LAFF_ATT_MUL)) return fail(LAFF_E_UNSUPPORTED, "laff_frame_fuse: flags 0x%x", flags);
+    if (!aligned16(frames) || !aligned16(w) || !aligned16(V)) return fail(LAFF_E_ALIGN, "laff_frame_fuse: 16-byte alignment");
+    if (B == 0) return LAFF_OK;
+    laff::FrameArgs a{frames, lens, B, Fmax, d, w, b, gw, flags, V};
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_frame_fuse(a, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_packed_bytes(int N, int K, int precision, size_t* out) {
+    if (!out || N < 0 || K < 0) return fail(LAFF_E_ARG, "laff_packed_bytes: bad args");
+    if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "laff_packed_bytes: bad precision %d", precision);
+    *out = (size_t)N * K * elem_size(precision) * (is_x3(precision) ? 2 : 1);
+    return LAFF_OK;
+}
+
+int laff_pack_rows(laff_ctx* ctx, const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,
+                   int precision, void* out) {
+    CHECK_CTX(ctx);
+    if (!E || !out) return fail(LAFF_E_ARG, "laff_pack_rows: null E/out");
+    if (N < 0 || H < 1 || d < 4 || (d & 3) || lde < H * d || (lde & 3))
+        return fail(LAFF_E_SHAPE, "laff_pack_rows: bad shape N=%d H=%d d=%d lde=%d", N, H, d, lde);
+    if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "laff_pack_rows: bad precision %d", precision);
+    if (!aligned16(E) || !aligned16(out)) return fail(LAFF_E_ALIGN, "laff_pack_rows: 16-byte alignment");
+    if (N == 0) return LAFF_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_pack_rows(E, N, H, d, lde, normalize, eps, prescale, precision, out, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
+                  float* S, int lds, const int* gt_col, int col0, const float* s_gt, int* count) {
+    CHECK_CTX(ctx);
+    if (!T || !V) return fail(LAFF_E_ARG, "laff_sim_gemm: null T/V");
+    if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "laff_sim_gemm: bad precision %d", precision);
+    const int kmul = precision == LAFF_PREC_FP32 ? 32 : 64;
+    if (Nt < 0 || Nv < 0 || K < kmul || (K % kmul)) return fail(LAFF_E_SHAPE, "laff_sim_gemm: need K%%%d==0 (Nt=%d Nv=%d K=%d)", kmul, Nt, Nv, K);
+    if (!S && !gt_col) return fail(LAFF_E_ARG, "laff_sim_gemm: nothing to produce (S and gt_col both null)");
+    if (S && lds < Nv) return fail(LAFF_E_SHAPE, "laff_sim_gemm: lds=%d < Nv=%d", lds, Nv);
+    if (gt_col && (!s_gt || !count)) return fail(LAFF_E_ARG, "laff_sim_gemm: gt_col needs s_gt and count");
+    if (!aligned16(T) || !aligned16(V)) return fail(LAFF_E_ALIGN, "laff_sim_gemm: operands must be 16-byte aligned");
+    if (Nt == 0 || Nv == 0) return LAFF_OK;
+    laff::GemmArgs a{};
+    a.R = T; a.C = V; a.nR = Nt; a.nC = Nv; a.K = K; a.ldR = K; a.ldC = K;
+    const long planeT = (long)Nt * K * 2, planeV = (long)Nv * K * 2;
+    if (is_x3(precision)) {
+        // virtual K concatenation: lo*hi, hi*lo first (small terms), hi*hi last
+        a.nseg = 3;
+        a.segR[0] = planeT; a.segC[0] = 0;
+        a.segR[1] = 0;      a.segC[1] = planeV;
+        a.segR[2] = 0;      a.segC[2] = 0;
+    } else {
+        a.nseg = 1; a.segR[0] = a.segC[0] = 0;
+    }
+    a.out = S; a.ldo = lds; a.scale = scale;
+    a.gt_col = gt_col; a.col0 = col0; a.s_gt = s_gt; a.count = gt_col ? count : nullptr;
+    int mode = laff::GEMM_F32;
+    if (precision == LAFF_PREC_FP16 || precision == LAFF_PREC_FP16X3) mode = laff::GEMM_F16;
+    if (precision == LAFF_PREC_BF16 || precision == LAFF_PREC_BF16X3) mode = laff::GEMM_BF16;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_gemm_nt(a, mode, true, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_gather_gt(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt) {
+    CHECK_CTX(ctx);
+    if (!S || !gt_col || !s_gt) return fail(LAFF_E_ARG, "laff_gather_gt: null argument");
+    if (Nt < 0 || Nv < 0 || lds < Nv) return fail(LAFF_E_SHAPE, "laff_gather_gt: bad shape");
+    if (Nt == 0) return LAFF_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_gather_gt(S, Nt, Nv, lds, gt_col, col0, s_gt, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_rank_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0,
+                    const float* s_gt, int* count, int accumulate) {
+    CHECK_CTX(ctx);
+    if (!S || !gt_col || !s_gt || !count) return fail(LAFF_E_ARG, "laff_rank_count: null argument");
+    if (Nt < 0 || Nv < 0 || lds < Nv) return fail(LAFF_E_SHAPE, "laff_rank_count: bad shape");
+    if (Nt == 0) return LAFF_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_rank_count(S, Nt, Nv, lds, gt_col, col0, s_gt, count, accumulate, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx,
+                   int max_group, int* count) {
+    CHECK_CTX(ctx);
+    if (!S || !grp_off || !grp_idx || !count) return fail(LAFF_E_ARG, "laff_v2t_count: null argument");
+    if (Nt < 0 || Nv < 0 || lds < Nv || max_group < 0) return fail(LAFF_E_SHAPE, "laff_v2t_count: bad shape");
+    if (Nt == 0 || Nv == 0 || max_group == 0) return LAFF_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_v2t_count(S, Nt, Nv, lds, grp_off, grp_idx, max_group, count, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, double out7[7]) {
+    CHECK_CTX(ctx);
+    if (!rank1 || !out7) return fail(LAFF_E_ARG, "laff_rank_metrics: null argument");
+    if (Nq < 1) return fail(LAFF_E_SHAPE, "laff_rank_metrics: Nq=%d", Nq);
+    DeviceGuard g(ctx->device);
+    std::vector<int> r(Nq);
+    HIP_TRY(hipMemcpyAsync(r.data(), rank1, sizeof(int) * (size_t)Nq, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // evaluation.eval (/root/reference/evaluation.py:92-109) with one ground truth per row: AP = 1/rank
+    double c1 = 0, c5 = 0, c10 = 0, sum = 0, isum = 0;
+    for (int i = 0; i < Nq; ++i) {
+        const int v = r[i];
+        if (v < 1) return fail(LAFF_E_ARG, "laff_rank_metrics: rank1[%d]=%d is not 1-based", i, v);
+        c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
+        sum += v; isum += 1.0 / v;
+    }
+    std::vector<int> s(r);
+    const size_t mid = (size_t)Nq / 2;
+    std::nth_element(s.begin(), s.begin() + mid, s.end());
+    double med = s[mid];
+    if ((Nq & 1) == 0) {
+        const int lo = *std::max_element(s.begin(), s.begin() + mid);
+        med = 0.5 * (med + lo);
+    }
+    out7[0] = 100.0 * c1 / Nq; out7[1] = 100.0 * c5 / Nq; out7[2] = 100.0 * c10 / Nq;
+    out7[3] = std::floor(med); out7[4] = sum / Nq; out7[5] = isum / Nq; out7[6] = isum / Nq;
+    return LAFF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,458 @@
+// fuse.hip -- HBM-bound kernels of the LAFF hot path (gfx950): attention fusion over <= 8 feature planes,
+// per-video frame attention, row normalisation + 16-bit operand packing.
+//
+// Reference arithmetic (all fp32; file:line under /root/reference):
+//   Attention_1.forward                     model/Attention.py:78-105
+//   Multi_head_MyApply_Attention.forward    model/Attention.py:508-531
+//   no-transform branch (repeat + BN)       model/model.py:1801-1805, 1822-1823, 659-664, 1675-1676
+//   frame attention loop                    model/model.py:2163-2173
+//   loss.l2norm                             loss.py:8-13
+//
+// Mapping: one 64-lane wavefront per (row n, head h).  Lane i owns columns {256*j + 4*i .. +3} of the head
+// (16-byte loads, 1 KiB contiguous per wave-instruction); the <= 8 softmax logits are reduced across the
+// wave with xor-shuffles and the softmax itself is computed redundantly in every lane's registers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace laff {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 scl4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 fma4(float4 a, float s, float4 c) {
+    return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// x_l[n,h,col..col+3] with the plane's tiling and folded affine applied
+__device__ __forceinline__ float4 load_plane(const FuseArgs& a, int l, long n, int h, int col) {
+    const int srccol = a.tile[l] ? col : h * a.head_stride + col;
+    float4 v = *(const float4*)(a.src[l] + n * a.ld[l] + srccol);
+    if (a.scale[l]) {
+        const int ai = a.tile[l] ? h * a.d + col : srccol;
+        const float4 s = *(const float4*)(a.scale[l] + ai);
+        const float4 t = *(const float4*)(a.shift[l] + ai);
+        v = make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
+    }
+    return v;
+}
+
+// softmax over L logits held identically by every lane
+template <int L>
+__device__ __forceinline__ void softmax_L(float (&lg)[L]) {
+    float m = lg[0];
+#pragma unroll
+    for (int l = 1; l < L; ++l) m = fmaxf(m, lg[l]);
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        lg[l] = expf(lg[l] - m);
+        s += lg[l];
+    }
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int l = 0; l < L; ++l) lg[l] *= inv;
+}
+
+// ---- register-resident variant: d <= 256*NCH ----------------------------------------------------------------
+template <int L, int NCH>
+__global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)a.N * a.H) return;
+    const long n = item / a.H;
+    const int h = (int)(item - n * a.H);
+    const int d = a.d;
+
+    float4 x[L][NCH];
+    float4 wv[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int col = j * 256 + lane * 4;
+        const bool ok = col < d;
+        wv[j] = ok ? *(const float4*)(a.w + (long)h * d + col) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) x[l][j] = ok ? load_plane(a, l, n, h, col) : make_float4(0, 0, 0, 0);
+    }
+    if (a.flags & LAFF_ATT_L2NORM_EACH_HEAD) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) ss += dot4(x[l][j], x[l][j]);
+            const float inv = 1.0f / (sqrtf(wave_sum(ss)) + 1e-13f + 1e-14f);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) x[l][j] = scl4(x[l][j], inv);
+        }
+    }
+    float4 sum[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        sum[j] = x[0][j];
+#pragma unroll
+        for (int l = 1; l < L; ++l) sum[j] = add4(sum[j], x[l][j]);
+    }
+    float4 g[NCH];
+    float lg[L];
+    if (a.flags & LAFF_ATT_JUST_AVERAGE) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) g[j] = scl4(sum[j], 1.0f / L);
+    } else {
+        const bool mul = a.flags & LAFF_ATT_MUL;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            float p = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const float4 c = mul ? mul4(x[l][j], scl4(sum[j], 1.0f / L)) : x[l][j];
+                p += dot4(c, wv[j]);
+            }
+            lg[l] = wave_sum(p) + a.b[h];
+        }
+        softmax_L<L>(lg);
+        const float ave = (a.flags & LAFF_ATT_WITH_AVE) ? a.gw[h] : 0.0f;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            g[j] = scl4(x[0][j], lg[0]);
+#pragma unroll
+            for (int l = 1; l < L; ++l) g[j] = fma4(x[l][j], lg[l], g[j]);
+            g[j] = fma4(sum[j], ave, g[j]);
+            ss += dot4(g[j], g[j]);
+        }
+        const float inv = 1.0f / (sqrtf(wave_sum(ss)) + 1e-14f);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) g[j] = scl4(g[j], inv);
+        if (a.attn_w && lane < L) {
+            float v = lg[0];
+#pragma unroll
+            for (int l = 1; l < L; ++l) v = (lane == l) ? lg[l] : v;
+            a.attn_w[item * L + lane] = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int col = j * 256 + lane * 4;
+        if (col < d) *(float4*)(a.E + item * d + col) = g[j];
+    }
+}
+
+// ---- streaming variant: any d % 4 == 0 (planes re-read from L2; used for d > 512) -----------------------------
+template <int L>
+__global__ __launch_bounds__(256) void fuse_stream_kernel(FuseArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)a.N * a.H) return;
+    const long n = item / a.H;
+    const int h = (int)(item - n * a.H);
+    const int d = a.d;
+    float invn[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) invn[l] = 1.0f;
+    if (a.flags & LAFF_ATT_L2NORM_EACH_HEAD) {
+        float ss[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) ss[l] = 0.f;
+        for (int col = lane * 4; col < d; col += 256)
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const float4 v = load_plane(a, l, n, h, col);
+                ss[l] += dot4(v, v);
+            }
+#pragma unroll
+        for (int l = 0; l < L; ++l) invn[l] = 1.0f / (sqrtf(wave_sum(ss[l])) + 1e-13f + 1e-14f);
+    }
+    float lg[L];
+    const bool javg = a.flags & LAFF_ATT_JUST_AVERAGE;
+    if (!javg) {
+        const bool mul = a.flags & LAFF_ATT_MUL;
+        float p[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) p[l] = 0.f;
+        for (int col = lane * 4; col < d; col += 256) {
+            const float4 wv = *(const float4*)(a.w + (long)h * d + col);
+            float4 xv[L];
+            float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                xv[l] = scl4(load_plane(a, l, n, h, col), invn[l]);
+                s = add4(s, xv[l]);
+            }
+            s = scl4(s, 1.0f / L);
+#pragma unroll
+            for (int l = 0; l < L; ++l) p[l] += dot4(mul ? mul4(xv[l], s) : xv[l], wv);
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) lg[l] = wave_sum(p[l]) + a.b[h];
+        softmax_L<L>(lg);
+        if (a.attn_w && lane < L) {
+            float v = lg[0];
+#pragma unroll
+            for (int l = 1; l < L; ++l) v = (lane == l) ? lg[l] : v;
+            a.attn_w[item * L + lane] = v;
+        }
+    }
+    const float ave = (!javg && (a.flags & LAFF_ATT_WITH_AVE)) ? a.gw[h] : 0.0f;
+    float ss = 0.f;
+    for (int col = lane * 4; col < d; col += 256) {
+        float4 g = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float4 xv = scl4(load_plane(a, l, n, h, col), invn[l]);
+            g = fma4(xv, javg ? 1.0f / L : lg[l] + ave, g);
+        }
+        ss += dot4(g, g);
+        *(float4*)(a.E + item * d + col) = g;
+    }
+    if (javg) return;
+    const float inv = 1.0f / (sqrtf(wave_sum(ss)) + 1e-14f);
+    // each lane rescales exactly the elements it wrote itself
+    for (int col = lane * 4; col < d; col += 256) {
+        float4* e = (float4*)(a.E + item * d + col);
+        *e = scl4(*e, inv);
+    }
+}
+
+template <int L>
+static hipError_t launch_fuse_L(const FuseArgs& a, hipStream_t st) {
+    const long items = (long)a.N * a.H;
+    const unsigned grid = (unsigned)((items + 3) / 4);
+    if (a.d <= 256)
+        hipLaunchKernelGGL((fuse_reg_kernel<L, 1>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.d <= 512)
+        hipLaunchKernelGGL((fuse_reg_kernel<L, 2>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((fuse_stream_kernel<L>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fuse(const FuseArgs& a, hipStream_t st) {
+    switch (a.L) {
+        case 1: return launch_fuse_L<1>(a, st);
+        case 2: return launch_fuse_L<2>(a, st);
+        case 3: return launch_fuse_L<3>(a, st);
+        case 4: return launch_fuse_L<4>(a, st);
+        case 5: return launch_fuse_L<5>(a, st);
+        case 6: return launch_fuse_L<6>(a, st);
+        case 7: return launch_fuse_L<7>(a, st);
+        case 8: return launch_fuse_L<8>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- frame attention: one 256-thread workgroup per video ------------------------------------------------------
+// Wave w walks frames w, w+4, ...; online softmax per wave, merged through LDS.  Columns: lane i owns
+// {256*j + 4*i .. +3}, j < NCH (d <= 1024).
+template <int NCH>
+__global__ __launch_bounds__(256) void frame_fuse_kernel(FrameArgs a) {
+    __shared__ __attribute__((aligned(16))) float sh_acc[4][NCH * 256];
+    __shared__ __attribute__((aligned(16))) float sh_sum[4][NCH * 256];
+    __shared__ float sh_m[4], sh_s[4], sh_red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bidx = blockIdx.x;
+    const int d = a.d, Fmax = a.Fmax;
+    const int len = a.lens ? min(max(a.lens[bidx], 0), Fmax) : Fmax;
+    const float* base = a.frames + (long)bidx * Fmax * d;
+    const bool mul = a.flags & LAFF_ATT_MUL;
+    const bool with_ave = a.flags & LAFF_ATT_WITH_AVE;
+    const float bias = a.b[0];
+
+    float4 wv[NCH], xs[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int col = j * 256 + lane * 4;
+        wv[j] = col < d ? *(const float4*)(a.w + col) : make_float4(0, 0, 0, 0);
+        xs[j] = make_float4(0, 0, 0, 0);
+    }
+    if (mul) {
+        // mean over ALL Fmax frames (padded zeros included, as in the reference): w <- w * sum_f x_f / Fmax
+        for (int f = wave; f < len; f += 4)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int col = j * 256 + lane * 4;
+                if (col < d) xs[j] = add4(xs[j], *(const float4*)(base + (long)f * d + col));
+            }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) *(float4*)&sh_sum[wave][j * 256 + lane * 4] = xs[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            float4 t = add4(add4(*(float4*)&sh_sum[0][c], *(float4*)&sh_sum[1][c]),
+                            add4(*(float4*)&sh_sum[2][c], *(float4*)&sh_sum[3][c]));
+            wv[j] = mul4(wv[j], scl4(t, 1.0f / Fmax));
+            xs[j] = make_float4(0, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float m = -INFINITY, s = 0.f;
+    float4 acc[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) acc[j] = make_float4(0, 0, 0, 0);
+    for (int f = wave; f < len; f += 4) {
+        float4 xv[NCH];
+        float p = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int col = j * 256 + lane * 4;
+            xv[j] = col < d ? *(const float4*)(base + (long)f * d + col) : make_float4(0, 0, 0, 0);
+            p += dot4(xv[j], wv[j]);
+        }
+        const float lg = wave_sum(p) + bias;
+        const float mn = fmaxf(m, lg);
+        const float r = expf(m - mn), e = expf(lg - mn);
+        s = s * r + e;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            acc[j] = fma4(xv[j], e, scl4(acc[j], r));
+            xs[j] = add4(xs[j], xv[j]);
+        }
+        m = mn;
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        *(float4*)&sh_acc[wave][j * 256 + lane * 4] = acc[j];
+        *(float4*)&sh_sum[wave][j * 256 + lane * 4] = xs[j];
+    }
+    if (lane == 0) {
+        sh_m[wave] = m;
+        sh_s[wave] = s;
+    }
+    __syncthreads();
+    // merge the four partial softmaxes + the (Fmax - len) padded frames whose logit is exactly `bias`
+    float M = fmaxf(fmaxf(sh_m[0], sh_m[1]), fmaxf(sh_m[2], sh_m[3]));
+    const int npad = Fmax - len;
+    if (npad > 0) M = fmaxf(M, bias);
+    float S = npad > 0 ? npad * expf(bias - M) : 0.f;
+    float sc[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        sc[w] = (sh_m[w] == -INFINITY) ? 0.f : expf(sh_m[w] - M);
+        S += sh_s[w] * sc[w];
+    }
+    const float invS = 1.0f / S;
+    const float ave = with_ave ? a.gw[0] : 0.f;
+    // threads 0..d/4-1 of the block each finish one float4 of the output
+    float ss = 0.f;
+    float4 g = make_float4(0, 0, 0, 0);
+    const int c4 = threadIdx.x * 4;
+    constexpr int PER = 1;     // d <= 1024 columns = 256 threads x one float4
+    float4 gq[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int c = q * 1024 + c4;
+        gq[q] = make_float4(0, 0, 0, 0);
+        if (c < d) {
+            float4 t = make_float4(0, 0, 0, 0), u = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                t = fma4(*(float4*)&sh_acc[w][c], sc[w], t);
+                u = add4(u, *(float4*)&sh_sum[w][c]);
+            }
+            g = fma4(u, ave, scl4(t, invS));
+            gq[q] = g;
+            ss += dot4(g, g);
+        }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) sh_red[wave] = ss;
+    __syncthreads();
+    const float inv = 1.0f / (sqrtf(sh_red[0] + sh_red[1] + sh_red[2] + sh_red[3]) + 1e-14f);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int c = q * 1024 + c4;
+        if (c < d) *(float4*)(a.V + (long)bidx * d + c) = scl4(gq[q], inv);
+    }
+}
+
+hipError_t launch_frame_fuse(const FrameArgs& a, hipStream_t st) {
+    if (a.d <= 256)
+        hipLaunchKernelGGL((frame_fuse_kernel<1>), dim3(a.B), dim3(256), 0, st, a);
+    else if (a.d <= 512)
+        hipLaunchKernelGGL((frame_fuse_kernel<2>), dim3(a.B), dim3(256), 0, st, a);
+    else if (a.d <= 1024)
+        hipLaunchKernelGGL((frame_fuse_kernel<4>), dim3(a.B), dim3(256), 0, st, a);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---- row normalisation + packing --------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ E, int N, int H, int d, int lde,
+                                                        int normalize, float eps, float prescale, void* out) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)N * H) return;
+    const long n = item / H;
+    const int h = (int)(item - n * H);
+    const float* src = E + n * lde + (long)h * d;
+    const long K = (long)H * d;
+    float mult = prescale;
+    if (normalize) {
+        float ss = 0.f;
+        for (int col = lane * 4; col < d; col += 256) {
+            const float4 v = *(const float4*)(src + col);
+            ss += dot4(v, v);
+        }
+        mult = prescale / (sqrtf(wave_sum(ss)) + eps + 1e-14f);
+    }
+    for (int col = lane * 4; col < d; col += 256) {
+        const float4 v = scl4(*(const float4*)(src + col), mult);
+        const long o = n * K + (long)h * d + col;
+        if constexpr (PREC == LAFF_PREC_FP32) {
+            *(float4*)((float*)out + o) = v;
+        } else if constexpr (PREC == LAFF_PREC_FP16 || PREC == LAFF_PREC_FP16X3) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 hi = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *(h4*)((_Float16*)out + o) = hi;
+            if constexpr (PREC == LAFF_PREC_FP16X3) {
+                h4 lo = {(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
+                         (_Float16)(v.w - (float)hi[3])};
+                *(h4*)((_Float16*)out + (long)N * K + o) = lo;
+            }
+        } else {
+            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+            b4 hi = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+            *(b4*)((__bf16*)out + o) = hi;
+            if constexpr (PREC == LAFF_PREC_BF16X3) {
+                b4 lo = {(__bf16)(v.x - (float)hi[0]), (__bf16)(v.y - (float)hi[1]), (__bf16)(v.z - (float)hi[2]),
+                         (__bf16)(v.w - (float)hi[3])};
+                *(b4*)((__bf16*)out + (long)N * K + o) = lo;
+            }
+        }
+    }
+}
+
+hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,
+                            int precision, void* out, hipStream_t st) {
+    const long items = (long)N * H;
+    const unsigned grid = (unsigned)((items + 3) / 4);
+#define LAFF_PACK(P)                                                                                                \
+    hipLaunchKernelGGL((pack_rows_kernel<P>), dim3(grid), dim3(256), 0, st, E, N, H, d, lde, normalize, eps, prescale, \
+                       out)
+    switch (precision) {
+        case LAFF_PREC_FP32: LAFF_PACK(LAFF_PREC_FP32); break;
+        case LAFF_PREC_FP16: LAFF_PACK(LAFF_PREC_FP16); break;
+        case LAFF_PREC_BF16: LAFF_PACK(LAFF_PREC_BF16); break;
+        case LAFF_PREC_FP16X3: LAFF_PACK(LAFF_PREC_FP16X3); break;
+        case LAFF_PREC_BF16X3: LAFF_PACK(LAFF_PREC_BF16X3); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef LAFF_PACK
+    return hipGetLastError();
+}
+
+}  // namespace laff

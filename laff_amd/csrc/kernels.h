@@ -1,0 +1,76 @@
+// kernels.h -- internal launch interface between api.hip and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/laff_hip.h"
+
+namespace laff {
+
+enum { GEMM_F32 = 0, GEMM_F16 = 1, GEMM_BF16 = 2 };
+
+struct GemmArgs {
+    const void* R;        // [nR, ldR] rows -> output rows
+    const void* C;        // [nC, ldC] rows -> output columns
+    int nR, nC, K;        // K in elements (per segment)
+    int ldR, ldC;         // elements
+    int nseg;             // 1, or 3 for the hi/lo split (virtual K concatenation)
+    long segR[3], segC[3];  // byte offset of the operand plane used by each segment
+    float* out;           // [nR, ldo] or null
+    int ldo;
+    float scale;
+    // FC epilogue
+    const float* bias;
+    const float* bn_scale;
+    const float* bn_shift;
+    int act;
+    // fused ground-truth rank count
+    const int* gt_col;
+    int col0;
+    const float* s_gt;
+    int* count;
+};
+
+hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool glds, hipStream_t st);
+
+constexpr int MAX_L = 8;
+struct FuseArgs {
+    const float* src[MAX_L];
+    const float* scale[MAX_L];
+    const float* shift[MAX_L];
+    int ld[MAX_L];
+    int tile[MAX_L];
+    int L, N, H, d;
+    int head_stride;      // d (split heads) or 0 (every head sees all columns)
+    const float* w;       // [H, d]
+    const float* b;       // [H]
+    const float* gw;      // [H]
+    unsigned flags;
+    float* E;             // [N, H, d]
+    float* attn_w;        // [N, H, L] or null
+};
+hipError_t launch_fuse(const FuseArgs& a, hipStream_t st);
+
+struct FrameArgs {
+    const float* frames;  // [B, Fmax, d]
+    const int* lens;      // [B] or null
+    int B, Fmax, d;
+    const float* w;
+    const float* b;
+    const float* gw;
+    unsigned flags;
+    float* V;             // [B, d]
+};
+hipError_t launch_frame_fuse(const FrameArgs& a, hipStream_t st);
+
+hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,
+                            int precision, void* out, hipStream_t st);
+
+hipError_t launch_gather_gt(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt,
+                            hipStream_t st);
+hipError_t launch_rank_count(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, const float* s_gt,
+                             int* count, int accumulate, hipStream_t st);
+hipError_t launch_v2t_count(const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx,
+                            int max_group, int* count, hipStream_t st);
+
+}  // namespace laff

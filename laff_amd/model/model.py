@@ -1,0 +1,566 @@
+"""Retrieval towers and predict() of the reference's model/model.py on the MI355X kernels.
+
+Same registry keys, class names, constructor/forward signatures, config attribute names and state_dict keys
+as /root/reference/model/model.py for the symbols on the hot path:
+
+  TransformNet                         :211-276     -> laff_fc_act_bn (fp32 MFMA GEMM + fused epilogue)
+  VisMutiTransformNet                  :1787-1827
+  VisMutiTransformNetAddAttnetion      :1830-1881   -> planes + one laff_fuse launch (no stack / repeat copies)
+  MultiScaleTxtEncoderAttention        :1641-1709
+  VisMutiTransformNetPlusFrameFeat     :2101-2194   -> laff_frame_fuse instead of the per-sample Python loop
+  W2VVPP.get_txt2vis_matrix / predict  :1003-1128   -> one laff_sim_gemm over all pairs instead of the
+                                                       (Nt/bs)x(Nv/bs) block loop; embeddings stay in HBM
+  get_model                            :2501-2519
+
+Inference only: training (forward(), losses, optimisers) is out of scope and raises.
+Text encoders (GRU / BoW / W2V / CLIP, :311-549) are upstream of the path: features arrive pre-extracted in
+`caption_feat_dict` (the reference already does this for frozen CLIP via 'CLIP_encoding', :497-498); any module
+returning {'text_features': tensor} can be plugged into `txt_net.encoder.<name>`.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import loss as _loss
+from .. import ops
+from .Attention import Attention_1, JustAverage, Multi_head_MyApply_Attention
+
+device = torch.device('cuda')
+float16 = False
+
+
+def _initialize_weights(m):
+    """Xavier init of Linear layers, identity BatchNorm (model/model.py:51-60)."""
+    if type(m) == nn.Linear:
+        nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif type(m) == nn.BatchNorm1d:
+        nn.init.ones_(m.weight)
+        nn.init.zeros_(m.bias)
+
+
+def to_device_and_float16(x):
+    """model/model.py:63-67: despite its name the reference never casts to fp16."""
+    return x.to(device=device, dtype=torch.float32)
+
+
+def _eval_only(module):
+    if module.training:
+        raise NotImplementedError('laff_amd implements the inference path only; call .eval() '
+                                  '(training is out of scope, SURVEY.md section 8f)')
+
+
+# ------------------------------------------------------------------------------------------------------
+# attention registry (model/model.py:70-208) -- only the variants on the path
+# ------------------------------------------------------------------------------------------------------
+_ATTENTION_1 = {  # name -> (with_ave, mul)   (model/model.py:94-97)
+    'attention_noAverageMul_Ave': (True, False),
+    'attention_noAveNoAverageMul': (False, False),
+    'attention_averageMul': (True, True),
+    'average_AverageMul_noAve': (False, True),
+}
+
+
+def get_attention_layer(attention_type, common_space_dim, encoder_num, opt):
+    if attention_type in _ATTENTION_1:
+        with_ave, mul = _ATTENTION_1[attention_type]
+        return Attention_1(common_space_dim, with_ave=with_ave, mul=mul)
+    if attention_type == 'just_average':
+        return JustAverage()
+    if attention_type == 'Multi_head_MyApply_Attention':
+        heads = opt.multi_head_attention['heads']
+        return Multi_head_MyApply_Attention(
+            common_space_dim, heads, common_space_dim // heads,
+            with_ave=opt.attention_param_each_head['with_ave'], mul=opt.attention_param_each_head['mul'],
+            split_head=opt.attention_param_each_head['split_head'], l2norm_each_head=opt.attention_l2norm)
+    raise NotImplementedError("attention type '%s' is an ablation variant outside the LAFF hot path" % attention_type)
+
+
+# ------------------------------------------------------------------------------------------------------
+# a1/a2: TransformNet
+# ------------------------------------------------------------------------------------------------------
+class TransformNet(nn.Module):
+    """fc -> activation -> dropout (identity in eval) -> BatchNorm1d, as one GEMM with a fused epilogue."""
+
+    def __init__(self, fc_layers, opt=None, dropout=None, batch_norm=None, activation=None, fc=True):
+        super().__init__()
+        if opt is not None:
+            if batch_norm is None:
+                batch_norm = opt.batch_norm
+            if activation is None:
+                activation = opt.activation
+            if dropout is None:
+                dropout = opt.dropout
+        self.fc1 = nn.Linear(fc_layers[0], fc_layers[1]) if fc else None
+        self.bn1 = nn.BatchNorm1d(fc_layers[1]) if batch_norm else None
+        self.activation_name = activation if activation in ('tanh', 'relu', 'sigmoid') else None
+        self.dropout_p = dropout if (dropout is not None and dropout > 1e-3) else None
+        self.out_features = fc_layers[1]
+        self._bn_cache = None
+        self.apply(_initialize_weights)
+
+    def bn_affine(self, extra_shift=None):
+        """Folded eval-mode BatchNorm1d: y*scale + shift (what aten's inference kernel computes)."""
+        if self.bn1 is None:
+            if extra_shift is None:
+                return None, None
+            return torch.ones_like(extra_shift), extra_shift.contiguous()
+        bn = self.bn1
+        ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if self._bn_cache is None or self._bn_cache[0] != key:
+            scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).contiguous()
+            shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+            self._bn_cache = (key, scale, shift)
+        scale, shift = self._bn_cache[1:]
+        if extra_shift is not None:
+            shift = (shift + extra_shift).contiguous()
+        return scale, shift
+
+    def plane(self, x, heads=1, extra_shift=None):
+        """(src, tile, scale, shift) for laff_fuse; runs the FC GEMM when there is one."""
+        _eval_only(self)
+        x = to_device_and_float16(x)
+        scale, shift = self.bn_affine(extra_shift)
+        if self.fc1 is not None:
+            y = ops.fc_act_bn(x, self.fc1.weight.detach(), self.fc1.bias.detach() if self.fc1.bias is not None else None,
+                              scale, shift, self.activation_name)
+            return (y, False, None, None)
+        if self.activation_name is not None:
+            raise NotImplementedError('activation without fc is never built by the reference towers')
+        tile = heads > 1 and x.shape[1] * heads == self.out_features
+        return (x, tile, scale, shift)
+
+    def forward(self, input_x):
+        src, tile, scale, shift = self.plane(input_x)
+        if scale is None and not tile:
+            return src
+        out = ops.fuse([(src, tile, scale, shift)], 1, src.shape[1], None, None, None,
+                       ops.attention_flags(just_average=True))
+        return out.view(out.shape[0], -1)
+
+
+# ------------------------------------------------------------------------------------------------------
+# a3/a4: video tower of 'LAFF' / 'w2vpp_mutivis_attention'
+# ------------------------------------------------------------------------------------------------------
+def _expert_rows(embedding, n):
+    return None if embedding is None else embedding.weight.detach()[:n]
+
+
+def _fuse(attention_layer, planes, heads):
+    if hasattr(attention_layer, 'fuse_planes'):
+        return attention_layer.fuse_planes(planes, heads)
+    raise NotImplementedError('attention layer %s is outside the LAFF hot path' % type(attention_layer).__name__)
+
+
+def _materialise(plane, heads, D):
+    src, tile, scale, shift = plane
+    if scale is None and not tile:
+        return src
+    H = heads if tile else 1
+    out = ops.fuse([plane], H, D // H, None, None, None, ops.attention_flags(just_average=True))
+    return out.view(out.shape[0], D)
+
+
+class VisMutiTransformNet(nn.Module):
+    def __init__(self, opt, space_dict):
+        super().__init__()
+        if opt is None:
+            return
+        self.opt = opt
+        self.vis_net_space_dict = space_dict
+        self.common_space_dim = opt.vis_fc_layers[1]
+        for each in space_dict.keys():
+            if each not in opt.vis_no_transform:
+                self.add_module(each, TransformNet((space_dict[each], opt.vis_fc_layers[1]), opt))
+            else:
+                self.add_module(each, TransformNet((space_dict[each], opt.vis_fc_layers[1]), None, dropout=None,
+                                                   batch_norm=True, activation=False, fc=False))
+
+    def planes(self, vis_input, expert=None):
+        if self.opt.vis_feat_add_concat and 'vis_feat_add_concat' not in vis_input:
+            vis_input['vis_feat_add_concat'] = torch.cat([to_device_and_float16(v) for v in vis_input.values()], dim=1)
+        heads = self.opt.multi_head_attention['heads']
+        module_dict = dict(self.named_children())
+        out = []
+        for i, name in enumerate(self.vis_net_space_dict.keys()):
+            vis_input[name] = to_device_and_float16(vis_input[name])     # in-place like the reference (:1817)
+            h = heads if name in self.opt.vis_no_transform else 1
+            out.append(module_dict[name].plane(vis_input[name], h, None if expert is None else expert[i]))
+        return out
+
+    def forward(self, vis_input, txt_emb=None, vis_frame_feat_dict_input=None):
+        heads = self.opt.multi_head_attention['heads']
+        planes = self.planes(vis_input)
+        return {name: _materialise(p, heads, self.common_space_dim)
+                for name, p in zip(self.vis_net_space_dict.keys(), planes)}
+
+
+class VisMutiTransformNetAddAttnetion(nn.Module):
+    def __init__(self, opt, space_dict):
+        super().__init__()
+        if opt is None:
+            return
+        self.opt = opt
+        self.vis_net_space_dict = space_dict
+        self.common_space_dim = opt.vis_fc_layers[1]
+        self.VisMutiTransformNet = VisMutiTransformNet(opt, space_dict)
+        self.attention_layer = get_attention_layer(self.opt.vis_attention, self.common_space_dim, len(space_dict), self.opt)
+        self.expert_embedding = None
+        self.expert_l2Norm = False
+        if opt.vis_expert_embedding['expert']:
+            self.expert_embedding = nn.Embedding(len(self.vis_net_space_dict), self.common_space_dim)
+        if opt.vis_expert_embedding['l2norm']:
+            raise NotImplementedError('vis_expert_embedding l2norm is off in every shipped config and not provided')
+
+    def forward(self, vis_input, txt_emb=None, vis_frame_feat_dict_input=None):
+        _eval_only(self)
+        planes = self.VisMutiTransformNet.planes(vis_input, _expert_rows(self.expert_embedding, len(self.vis_net_space_dict)))
+        return _fuse(self.attention_layer, planes, self.opt.multi_head_attention['heads'])
+
+    def get_attention_weight(self, vis_input, txt_emb=None):
+        self.forward(vis_input, txt_emb)
+        return self.attention_layer.get_attention_weight()
+
+
+# ------------------------------------------------------------------------------------------------------
+# text tower
+# ------------------------------------------------------------------------------------------------------
+class PreExtractedEncoder(nn.Module):
+    """Returns a pre-extracted text feature matrix from the caption dict (the reference's own convention for
+    frozen CLIP, model/model.py:497-498, extended to every text feature)."""
+
+    def __init__(self, key):
+        super().__init__()
+        self.key = key
+
+    def forward(self, caption_feat_dict, task3=False):
+        if self.key not in caption_feat_dict:
+            raise KeyError("caption_feat_dict lacks '%s': text features are pre-extracted on this path; plug an encoder "
+                           "module into txt_net.encoder to compute them on the fly" % self.key)
+        return {'text_features': caption_feat_dict[self.key]}
+
+
+class MultiScaleTxtEncoderAttention(nn.Module):
+    ENCODER_KEYS = {'rnn_encoder': 'rnn_encoding', 'bert_encoder': 'bert_encoding', 'bow_encoder': 'bow_encoding',
+                    'w2v_encoder': 'w2v_encoding', 'CLIP_encoder': 'CLIP_encoding', 'NetVLAD_encoder': 'NetVLAD_encoding'}
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        te = opt.text_encoding
+        bow, w2v, rnn, bert, clip_, vlad = (te[k]['name'] for k in ('bow_encoding', 'w2v_encoding', 'rnn_encoding',
+                                                                     'bert_encoding', 'CLIP_encoding', 'NetVLAD_encoding'))
+        rnn = rnn.split('_', 1)[0]
+        # encoder order is fixed by the reference (model/model.py:572-613): rnn, bert, bow, w2v, CLIP, NetVLAD
+        self.space_dict = {}
+        if rnn == 'gru':
+            self.space_dict['rnn_encoder'] = opt.rnn_size
+        elif rnn == 'bigru':
+            self.space_dict['rnn_encoder'] = opt.rnn_size * 2
+        if bert != 'noBert':
+            self.space_dict['bert_encoder'] = opt.bert_size
+        if 'no' not in bow:
+            self.space_dict['bow_encoder'] = opt.t2v_bow.ndims
+        if 'no' not in w2v:
+            self.space_dict['w2v_encoder'] = opt.t2v_w2v.ndims
+        if 'no' not in clip_:
+            self.space_dict['CLIP_encoder'] = opt.clip_opt['size']
+        if 'no' not in vlad:
+            self.space_dict['NetVLAD_encoder'] = opt.t2v_w2v.ndims * opt.NetVLAD_opt['num_clusters']
+        self.encoder = nn.Module()
+        for name in self.space_dict:
+            self.encoder.add_module(name, PreExtractedEncoder(self.ENCODER_KEYS[name]))
+        self.encoder_name_list = list(self.space_dict.keys())
+        self.txt_encoder_num = len(self.encoder_name_list)
+
+        # transform layers (model/model.py:622-681)
+        D = opt.txt_fc_layers[1]
+        self.transform_layer = nn.Module()
+        for name in ('rnn_encoder', 'bert_encoder', 'w2v_encoder', 'bow_encoder', 'CLIP_encoder', 'NetVLAD_encoder'):
+            if name not in self.space_dict:
+                continue
+            dims = (self.space_dict[name], D)
+            if name == 'bert_encoder':
+                t = TransformNet(dims, None, opt.bert_transform_dropout, opt.bert_transform_batch_norm,
+                                 opt.bert_transform_activation)
+            elif name == 'CLIP_encoder':
+                co = opt.clip_opt
+                if 'CLIP_encoder' in opt.txt_no_transform:
+                    t = TransformNet(dims, None, co['transform_dropout'], co['transform_batch_norm'], False, False)
+                else:
+                    t = TransformNet(dims, None, co['transform_dropout'], co['transform_batch_norm'],
+                                     co['transform_activation'])
+            else:
+                t = TransformNet(dims, None, opt.dropout, opt.batch_norm, opt.activation)
+            self.transform_layer.add_module(name + '_transform', t)
+        self.attention_layer = get_attention_layer(opt.txt_attention, D, self.txt_encoder_num, opt)
+
+        self.expert_embedding = None
+        if opt.txt_expert_embedding['expert']:
+            self.expert_embedding = nn.Embedding(len(self.space_dict), D)
+        if opt.txt_expert_embedding['l2norm']:
+            raise NotImplementedError('txt_expert_embedding l2norm is off in every shipped config and not provided')
+
+    def forward(self, caption_feat_dict, visual_emb=None, task3=False):
+        _eval_only(self)
+        heads = self.opt.multi_head_attention['heads']
+        expert = _expert_rows(self.expert_embedding, len(self.encoder_name_list))
+        planes = []
+        for i, name in enumerate(self.encoder_name_list):
+            feats = getattr(self.encoder, name)(caption_feat_dict, task3=task3)['text_features']
+            h = heads if name in self.opt.txt_no_transform else 1
+            planes.append(getattr(self.transform_layer, name + '_transform').plane(
+                feats, h, None if expert is None else expert[i]))
+        return _fuse(self.attention_layer, planes, heads)
+
+    def get_attention_weight(self, caption_feat_dict, visual_emb=None):
+        self.forward(caption_feat_dict, visual_emb)
+        return self.attention_layer.get_attention_weight()
+
+
+# ------------------------------------------------------------------------------------------------------
+# a7: FrameLAFF video tower
+# ------------------------------------------------------------------------------------------------------
+class VisMutiTransformNetPlusFrameFeat(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        space_dict = opt.vis_fc_layers[0]
+        if opt.frame_feat_input:
+            for frame_name in opt.vid_frame_feats:
+                space_dict[frame_name] = opt.vis_fc_layers[0][frame_name]
+        self.vis_net_space_dict = space_dict
+        for each in space_dict.keys():
+            if each not in opt.vis_no_transform:
+                self.add_module(each, TransformNet((space_dict[each], opt.vis_fc_layers[1]), opt))
+            else:
+                self.add_module(each, TransformNet((space_dict[each], opt.vis_fc_layers[1]), None, dropout=None,
+                                                   batch_norm=True, activation=False, fc=False))
+        D = opt.vis_fc_layers[1]
+        self.vis_attention_layer = get_attention_layer(opt.vis_attention, D, len(space_dict), opt)
+        self.frame_attention = nn.ModuleDict()
+        for each in opt.vid_frame_feats:
+            fd = opt.vis_fc_layers[0][each]
+            att = get_attention_layer(opt.vis_frame_attention, fd, 1, opt)
+            if not isinstance(att, Attention_1):
+                raise NotImplementedError('frame attention must be an Attention_1 variant on this path')
+            if opt.vis_frame_addFC:
+                self.frame_attention[each] = nn.Sequential(nn.Linear(fd, fd), att)
+            else:
+                self.frame_attention[each] = nn.Sequential(att)
+
+    def frame_vector(self, feat_name, frames, mask_tensor):
+        """(B, Fmax, d) zero-padded frames -> (B, d): Attention_1 over frames for every video in one launch.
+
+        Replaces the per-sample Python loop of model/model.py:2167-2173.  The reference's mask slice is a no-op, so
+        padded frames take part in softmax / mean; without a frame FC they are exact zeros and are accounted for
+        analytically from `lens`; with vis_frame_addFC the Linear turns them into the bias vector and all Fmax
+        frames are processed."""
+        seq = self.frame_attention[feat_name]
+        att = seq[-1]
+        frames = to_device_and_float16(frames).contiguous()
+        B, Fmax, d = frames.shape
+        lens = None
+        if len(seq) == 2:
+            fc = seq[0]
+            frames = ops.fc_act_bn(frames.view(B * Fmax, d), fc.weight.detach(), fc.bias.detach()).view(B, Fmax, d)
+        else:
+            lens = mask_tensor.to(device=frames.device).sum(dim=1).to(torch.int32).contiguous()
+        w, b, gw = att._params()
+        return ops.frame_fuse(frames, lens, w.reshape(-1), b, gw, ops.attention_flags(att.with_ave, att.mul))
+
+    def forward(self, vis_input, vis_frame_feat_dict_input, txt_emb=None):
+        _eval_only(self)
+        if self.opt.frame_feat_with_video_feat is False:
+            vis_input = {}
+        for feat_name in vis_frame_feat_dict_input:
+            if feat_name == 'mask_tensor':
+                continue
+            vis_frame_feat_dict_input[feat_name] = to_device_and_float16(vis_frame_feat_dict_input[feat_name])
+            vis_input[feat_name] = self.frame_vector(feat_name, vis_frame_feat_dict_input[feat_name],
+                                                     vis_frame_feat_dict_input['mask_tensor'])
+        heads = self.opt.multi_head_attention['heads']
+        module_dict = dict(self.named_children())
+        planes = []
+        for name in vis_input.keys():
+            vis_input[name] = to_device_and_float16(vis_input[name])
+            h = heads if name in self.opt.vis_no_transform else 1
+            planes.append(module_dict[name].plane(vis_input[name], h))
+        return _fuse(self.vis_attention_layer, planes, heads)
+
+    def get_attention_weight(self, vis_input, vis_frame_feat_dict_input):
+        self.forward(vis_input, vis_frame_feat_dict_input)
+        name = [k for k in vis_frame_feat_dict_input.keys() if k != 'mask_tensor'][0]
+        return self.frame_attention[name][-1].get_attention_weight()
+
+
+# ------------------------------------------------------------------------------------------------------
+# a9-a11: the cross-modal model
+# ------------------------------------------------------------------------------------------------------
+class W2VVPP(nn.Module):
+    """Inference surface of the reference's W2VVPP family (model/model.py:791-1128)."""
+
+    #: operand precision of the similarity GEMM ('fp32' | 'fp16' | 'bf16' | 'fp16x3' | 'bf16x3')
+    sim_precision = None
+
+    def _init_vis_net(self, opt):
+        raise NotImplementedError
+
+    def _init_txt_net(self, opt):
+        raise NotImplementedError
+
+    def __init__(self, opt):
+        super().__init__()
+        if opt is None:
+            return
+        self.opt = opt
+        self._init_vis_net(opt)
+        self._init_txt_net(opt)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('training step (model/model.py:964-1001) is out of scope; use predict()')
+
+    # -- towers ---------------------------------------------------------------------------------------------
+    def encode_video(self, vis_input, vis_frame_feat_dict=None):
+        """Alias named by BASELINE.json; = self.vis_net(vis_input, vis_frame_feat_dict_input=...)."""
+        with torch.no_grad():
+            return self.vis_net(vis_input, vis_frame_feat_dict_input=vis_frame_feat_dict if vis_frame_feat_dict is not None else {})
+
+    def encode_text(self, caption_feat_dict):
+        with torch.no_grad():
+            return self.txt_net(caption_feat_dict)
+
+    # -- similarity -----------------------------------------------------------------------------------------
+    @staticmethod
+    def compute_sim(query_embs, retro_embs, measure='cosine', device=None):
+        if measure != 'cosine':
+            raise NotImplementedError("measure '%s' is never configured on the path (base_config.py:92)" % measure)
+        dev = device if device is not None else globals()['device']
+        return _loss.cosine_sim(query_embs.to(dev), retro_embs.to(dev), W2VVPP.sim_precision)
+
+    def get_txt2vis_matrix(self, txt_embs, vis_embs, measure='cosine', precision=None):
+        """2-D: cosine; 3-D: mean over heads of per-head cosine == one GEMM over the concatenated,
+        per-head normalised embeddings divided by H."""
+        if measure != 'cosine':
+            raise NotImplementedError("measure '%s'" % measure)
+        if txt_embs.dim() != vis_embs.dim() or txt_embs.dim() not in (2, 3):
+            raise ValueError('txt_embs %s / vis_embs %s' % (tuple(txt_embs.shape), tuple(vis_embs.shape)))
+        precision = precision or self.sim_precision or _loss.DEFAULT_PRECISION
+        heads = txt_embs.shape[1] if txt_embs.dim() == 3 else 1
+        T = ops.pack_rows(to_device_and_float16(txt_embs).contiguous(), True, 1e-13, precision)
+        V = ops.pack_rows(to_device_and_float16(vis_embs).contiguous(), True, 1e-13, precision)
+        return ops.sim_gemm(T, V, heads=heads)
+
+    # -- predict --------------------------------------------------------------------------------------------
+    def _embed_videos(self, vis_loader):
+        embs, idxs_list, vis_ids = [], [], []
+        for output_dict in vis_loader:
+            vis_input, idxs, batch_vis_ids = output_dict['vis_feat_dict'], output_dict['idxs'], output_dict['vis_ids']
+            frame_dict = output_dict.get('vis_frame_feat_dict', {})
+            idxs_list.append(list(idxs))
+            embs.append(self.vis_net(vis_input, vis_frame_feat_dict_input=frame_dict))
+            vis_ids.extend(batch_vis_ids)
+        return torch.cat(embs, dim=0), idxs_list, vis_ids
+
+    def retrieve(self, txt_loader, vis_loader, measure='cosine', record_emb=False, precision=None):
+        """Device-resident version of predict(): returns (S_device (Nt,Nv) fp32, txt_ids, vis_ids)."""
+        if measure != 'cosine':
+            raise NotImplementedError("measure '%s'" % measure)
+        self.eval()
+        if not hasattr(self, 'video_all_embs'):
+            self.video_all_embs = None
+            self.video_idxs_list = []
+        with torch.no_grad():
+            if not record_emb or self.video_all_embs is None:
+                self.video_all_embs, self.video_idxs_list, self.vis_ids = self._embed_videos(vis_loader)
+            txt_ids, txt_embs = [], []
+            for caption_feat_dict, txt_idxs, batch_txt_ids in txt_loader:
+                txt_embs.append(self.txt_net(caption_feat_dict))
+                txt_ids.extend(batch_txt_ids)
+            txt_all = torch.cat(txt_embs, dim=0)
+            cols = np.concatenate([np.asarray(i, dtype=np.int64) for i in self.video_idxs_list])
+            vis_used = self.video_all_embs
+            identity = np.array_equal(cols, np.arange(len(cols)))
+            if not identity:   # the reference indexes the cached embeddings BY dataset index (:1066)
+                vis_used = self.video_all_embs[torch.as_tensor(cols, device=self.video_all_embs.device)]
+            S = self.get_txt2vis_matrix(txt_all, vis_used, measure, precision)
+            if not identity:
+                full = torch.zeros((S.shape[0], len(vis_loader.dataset)), device=S.device, dtype=S.dtype)
+                full[:, torch.as_tensor(cols, device=S.device)] = S
+                S = full
+        return S, txt_ids, self.vis_ids
+
+    def predict(self, txt_loader, vis_loader, measure, record_emb=False):
+        """Same contract as the reference (model/model.py:1018-1079): (np.float32[Nt,Nv] in loader row order,
+        txt_ids, vis_ids).  Embeddings stay in HBM, all pairs are scored by one GEMM, one D2H copy at the end."""
+        S, txt_ids, vis_ids = self.retrieve(txt_loader, vis_loader, measure, record_emb)
+        return S.cpu().numpy(), txt_ids, vis_ids
+
+    def predict_batch(self, txt_loader, vis_loader, measure, record_emb=False):
+        """The reference switches to a re-embedding loop above 5e4 videos to bound host memory (:1081-1128);
+        with 288 GB of HBM the single-pass path covers it, results are identical."""
+        return self.predict(txt_loader, vis_loader, measure, False)
+
+
+class W2VVPP_MutiVis(W2VVPP):
+    def _init_txt_net(self, opt):
+        if opt.txt_attention == 'concat':
+            raise NotImplementedError("txt_attention 'concat' (MultiScaleTxtNet) is outside the LAFF hot path")
+        self.txt_net = MultiScaleTxtEncoderAttention(opt)
+
+    def _init_vis_net(self, opt):
+        if opt.vis_attention == 'concat':
+            raise NotImplementedError("vis_attention 'concat' (VisTransformNet) is outside the LAFF hot path")
+        self.vis_net = VisMutiTransformNetAddAttnetion(opt, opt.vis_fc_layers[0])
+
+    def change_raw_global_emb_weight(self):
+        """Linear decay of gw, once per epoch in the reference (model/model.py:1910-1941)."""
+        for net, rate in ((self.txt_net, self.opt.txt_attention_global_decay_rate),
+                          (self.vis_net, self.opt.vis_attention_global_decay_rate)):
+            layer = getattr(net, 'attention_layer', None) or getattr(net, 'vis_attention_layer', None)
+            if layer is not None and hasattr(layer, 'get_raw_global_emb_weight'):
+                layer.change_raw_global_emb_weight(max(0.0, rate - 1 + layer.get_raw_global_emb_weight()))
+
+
+class W2VVPP_MultiHeadAttention(W2VVPP_MutiVis):
+    def get_txt2vis_matrix_each_head(self, txt_embs, vis_embs, measure='cosine'):
+        return torch.stack([self.get_txt2vis_matrix(txt_embs[:, h, :].contiguous(), vis_embs[:, h, :].contiguous(), measure)
+                            for h in range(txt_embs.shape[1])], dim=0)
+
+    def predict_each_head(self, txt_loader, vis_loader, measure):
+        """(H, Nt, Nv) per-head score cubes (model/model.py:2058-2098)."""
+        self.eval()
+        with torch.no_grad():
+            vis_all, idxs_list, vis_ids = self._embed_videos(vis_loader)
+            txt_ids, txt_embs = [], []
+            for caption_feat_dict, txt_idxs, batch_txt_ids in txt_loader:
+                txt_embs.append(self.txt_net(caption_feat_dict))
+                txt_ids.extend(batch_txt_ids)
+            scores = self.get_txt2vis_matrix_each_head(torch.cat(txt_embs, 0), vis_all, measure)
+        return scores.cpu().numpy(), txt_ids, vis_ids
+
+
+class W2VVPP_MutiVisFrameFeat(W2VVPP_MutiVis):
+    def _init_vis_net(self, opt):
+        self.vis_net = VisMutiTransformNetPlusFrameFeat(opt)
+
+
+def get_model(name, device_, config):
+    """Registry of the reference (model/model.py:2501-2519); keys outside the hot path are refused."""
+    global device
+    global float16
+    device = torch.device(device_)
+    float16 = config.float16
+    NAME_TO_MODELS = {
+        'FrameLAFF': W2VVPP_MutiVisFrameFeat,
+        'w2vpp_mutivis_attention': W2VVPP_MutiVis,
+        'LAFF': W2VVPP_MultiHeadAttention,
+    }
+    if name in ('W2VVPP', 'End2EndClip'):
+        raise NotImplementedError("model '%s' is outside the LAFF hot path (SURVEY.md section 2)" % name)
+    assert name in NAME_TO_MODELS, '%s not supported.' % name
+    model_ = NAME_TO_MODELS[name](config)
+    model_ = model_.float().to(device)
+    return model_

@@ -1,0 +1,223 @@
+"""Tensor-level wrappers over the C ABI (include/laff_hip.h).
+
+torch is used here for device memory and streams only: every function takes CUDA (ROCm) fp32 tensors,
+passes raw pointers to liblaff_hip.so on the current torch stream and returns torch tensors.  There is no
+CPU or eager-PyTorch fallback: CPU tensors are rejected.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
+                   Plane, check)
+
+__all__ = ['fc_act_bn', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+           'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
+
+_ctx = {}
+
+
+def _context(device):
+    """One laff_ctx per device ordinal, re-bound to torch's current stream at every call."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    lib = _lib.load()
+    if idx not in _ctx:
+        h = C.c_void_p()
+        check(lib.laff_ctx_create(idx, None, C.byref(h)))
+        _ctx[idx] = h
+    h = _ctx[idx]
+    check(lib.laff_ctx_set_stream(h, C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)))
+    return lib, h
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a CUDA (ROCm) tensor: laff_amd has no CPU path' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    return t
+
+
+def _rows(t, name):
+    """2-D view with unit inner stride; returns (tensor, ld)."""
+    _dev(t, name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError('%s must be 2-D with contiguous rows, got shape %s strides %s' % (name, tuple(t.shape), t.stride()))
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def attention_flags(with_ave=False, mul=False, l2norm_each_head=False, split_head=True, just_average=False):
+    return ((ATT_WITH_AVE if with_ave else 0) | (ATT_MUL if mul else 0) |
+            (ATT_L2NORM_EACH_HEAD if l2norm_each_head else 0) | (0 if split_head else ATT_NO_SPLIT_HEAD) |
+            (ATT_JUST_AVERAGE if just_average else 0))
+
+
+def fc_act_bn(x, weight, bias=None, bn_scale=None, bn_shift=None, activation=None, out=None):
+    """Y = act(x @ weight.T + bias) * bn_scale + bn_shift   (TransformNet.forward, eval mode)."""
+    x, ldx = _rows(x, 'x')
+    w, ldw = _rows(weight, 'weight')
+    N, Dk = x.shape
+    D = w.shape[0]
+    if w.shape[1] != Dk:
+        raise ValueError('weight is %s but x has %d columns' % (tuple(w.shape), Dk))
+    for t, nm in ((bias, 'bias'), (bn_scale, 'bn_scale'), (bn_shift, 'bn_shift')):
+        if t is not None:
+            _dev(t, nm)
+            if t.numel() != D or not t.is_contiguous():
+                raise ValueError('%s must be a contiguous vector of %d' % (nm, D))
+    if out is None:
+        out = torch.empty((N, D), device=x.device, dtype=torch.float32)
+    y, ldy = _rows(out, 'out')
+    lib, h = _context(x.device)
+    check(lib.laff_fc_act_bn(h, _ptr(x), N, Dk, ldx, _ptr(w), ldw, _ptr(bias), _ptr(bn_scale), _ptr(bn_shift), D,
+                             ACT[activation], _ptr(y), ldy))
+    return out
+
+
+def fuse(planes, H, d, w, b, gw, flags, return_weights=False):
+    """planes: list of (src[N, ld-view], tile, scale, shift).  Returns E (N, H, d) [and softmax weights (N, H, L)]."""
+    L = len(planes)
+    arr = (Plane * L)()
+    N = planes[0][0].shape[0]
+    keep = []
+    for i, (src, tile, scale, shift) in enumerate(planes):
+        src, ld = _rows(src, 'plane %d' % i)
+        if src.shape[0] != N:
+            raise ValueError('plane %d has %d rows, expected %d' % (i, src.shape[0], N))
+        need = d if (tile or (flags & ATT_NO_SPLIT_HEAD)) else H * d
+        if src.shape[1] != need:
+            raise ValueError('plane %d has %d columns, expected %d' % (i, src.shape[1], need))
+        for t in (scale, shift):
+            if t is not None:
+                _dev(t, 'plane affine')
+        arr[i] = Plane(src.data_ptr(), ld, 1 if tile else 0, scale.data_ptr() if scale is not None else None,
+                       shift.data_ptr() if shift is not None else None)
+        keep.append((src, scale, shift))
+    dev = planes[0][0].device
+    E = torch.empty((N, H, d), device=dev, dtype=torch.float32)
+    aw = torch.empty((N, H, L), device=dev, dtype=torch.float32) if return_weights else None
+    for t, nm in ((w, 'w'), (b, 'b'), (gw, 'gw')):
+        if t is not None:
+            _dev(t, nm)
+    lib, h = _context(dev)
+    check(lib.laff_fuse(h, arr, L, N, H, d, _ptr(w), _ptr(b), _ptr(gw), flags, _ptr(E), _ptr(aw)))
+    return (E, aw) if return_weights else E
+
+
+def frame_fuse(frames, lens, w, b, gw, flags):
+    """frames (B, Fmax, d) zero padded, lens int32 (B,) or None -> (B, d)."""
+    _dev(frames, 'frames')
+    if frames.dim() != 3 or not frames.is_contiguous():
+        raise ValueError('frames must be contiguous (B, Fmax, d)')
+    B, Fmax, d = frames.shape
+    if lens is not None:
+        _dev(lens, 'lens', torch.int32)
+        if lens.numel() != B:
+            raise ValueError('lens must have %d entries' % B)
+    V = torch.empty((B, d), device=frames.device, dtype=torch.float32)
+    lib, h = _context(frames.device)
+    check(lib.laff_frame_fuse(h, _ptr(frames), _ptr(lens), B, Fmax, d, _ptr(_dev(w, 'w')), _ptr(_dev(b, 'b')),
+                              _ptr(gw), flags, _ptr(V)))
+    return V
+
+
+def default_prescale(precision):
+    """fp16 operands are pre-scaled by 64 (exact) so that the low part of the hi/lo split stays normal."""
+    return 64.0 if precision in ('fp16', 'fp16x3') else 1.0
+
+
+class Packed:
+    """GEMM operand produced by pack_rows: raw 16/32-bit buffer + its logical shape and precision."""
+
+    def __init__(self, buf, N, K, precision, prescale):
+        self.buf, self.N, self.K, self.precision, self.prescale = buf, N, K, precision, prescale
+
+
+def pack_rows(E, normalize=True, eps=1e-13, precision='fp16', prescale=None):
+    """E (N, H, d) or (N, d): per-(row, head) l2norm (loss.l2norm) then conversion to the GEMM operand format."""
+    _dev(E, 'E')
+    if E.dim() == 2:
+        E = E.unsqueeze(1)
+    if E.dim() != 3 or E.stride(2) != 1 or E.stride(1) != E.shape[2]:
+        raise ValueError('E must be (N, H, d) with contiguous heads')
+    N, H, d = E.shape
+    lde = E.stride(0) if N > 1 else H * d
+    if prescale is None:
+        prescale = default_prescale(precision)
+    lib, h = _context(E.device)
+    nbytes = C.c_size_t()
+    check(lib.laff_packed_bytes(N, H * d, PREC[precision], C.byref(nbytes)))
+    buf = torch.empty((max(nbytes.value, 16),), device=E.device, dtype=torch.uint8)
+    check(lib.laff_pack_rows(h, _ptr(E), N, H, d, lde, 1 if normalize else 0, eps, prescale, PREC[precision], _ptr(buf)))
+    return Packed(buf, N, H * d, precision, prescale)
+
+
+def sim_gemm(T, V, heads=1, out=None, want_scores=True, gt_col=None, s_gt=None, count=None, col0=0):
+    """S = T.V^T / (heads * prescale^2) on Packed operands; optional fused ground-truth rank count."""
+    if T.precision != V.precision or T.K != V.K:
+        raise ValueError('operands differ in precision or K')
+    dev = T.buf.device
+    S = None
+    lds = V.N
+    if want_scores:
+        S = out if out is not None else torch.empty((T.N, V.N), device=dev, dtype=torch.float32)
+        S, lds = _rows(S, 'out')
+        if tuple(S.shape) != (T.N, V.N):
+            raise ValueError('out must be (%d, %d)' % (T.N, V.N))
+    if gt_col is not None:
+        _dev(gt_col, 'gt_col', torch.int32)
+        _dev(s_gt, 's_gt')
+        _dev(count, 'count', torch.int32)
+    scale = 1.0 / (heads * T.prescale * V.prescale)
+    lib, h = _context(dev)
+    check(lib.laff_sim_gemm(h, _ptr(T.buf), _ptr(V.buf), T.N, V.N, T.K, scale, PREC[T.precision], _ptr(S), lds,
+                            _ptr(gt_col), col0, _ptr(s_gt), _ptr(count)))
+    return S
+
+
+def gather_gt(S, gt_col, col0=0):
+    S, lds = _rows(S, 'S')
+    _dev(gt_col, 'gt_col', torch.int32)
+    out = torch.empty((S.shape[0],), device=S.device, dtype=torch.float32)
+    lib, h = _context(S.device)
+    check(lib.laff_gather_gt(h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(gt_col), col0, _ptr(out)))
+    return out
+
+
+def rank_count(S, gt_col, s_gt, col0=0, count=None):
+    S, lds = _rows(S, 'S')
+    _dev(gt_col, 'gt_col', torch.int32)
+    _dev(s_gt, 's_gt')
+    acc = count is not None
+    if count is None:
+        count = torch.empty((S.shape[0],), device=S.device, dtype=torch.int32)
+    _dev(count, 'count', torch.int32)
+    lib, h = _context(S.device)
+    check(lib.laff_rank_count(h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(gt_col), col0, _ptr(s_gt), _ptr(count),
+                              1 if acc else 0))
+    return count
+
+
+def v2t_count(S, grp_off, grp_idx, max_group):
+    S, lds = _rows(S, 'S')
+    _dev(grp_off, 'grp_off', torch.int32)
+    _dev(grp_idx, 'grp_idx', torch.int32)
+    count = torch.zeros((S.shape[0],), device=S.device, dtype=torch.int32)
+    lib, h = _context(S.device)
+    check(lib.laff_v2t_count(h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(grp_off), _ptr(grp_idx), int(max_group),
+                             _ptr(count)))
+    return count
+
+
+def rank_metrics(rank1):
+    """(r1, r5, r10, medr, meanr, mir, mAP) from 1-based int32 device ranks; synchronises the stream."""
+    _dev(rank1, 'rank1', torch.int32)
+    out = (C.c_double * 7)()
+    lib, h = _context(rank1.device)
+    check(lib.laff_rank_metrics(h, _ptr(rank1.contiguous()), rank1.numel(), out))
+    return tuple(out)

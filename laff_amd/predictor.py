@@ -1,0 +1,79 @@
+"""The ranking half of the reference's predictor.get_predict_file (/root/reference/predictor.py:232-276) on the GPU.
+
+The reference argsorts the (Nt, Nv) score matrix on the host, builds an (Nt, Nv) float64 label matrix with a
+per-query Python loop of numpy string comparisons, and hands it to evaluation.eval -- twice (T2V and V2T).
+Here ids are matched once through a dict, ranks are counted on the device straight from the score matrix
+(position = 1 + #{strictly greater}), and only Nt integers come back to the host.
+"""
+import numpy as np
+import torch
+
+from . import evaluation, ops
+
+
+def gt_columns(txt_ids, vis_ids):
+    """owner[t] = column of the video named by `txt_id.split('#')[0]` (predictor.py:241)."""
+    index = {}
+    for i, v in enumerate(vis_ids):
+        if v in index:
+            raise ValueError("video id '%s' appears twice in vis_ids" % v)
+        index[v] = i
+    try:
+        return np.fromiter((index[t.split('#')[0]] for t in txt_ids), dtype=np.int32, count=len(txt_ids))
+    except KeyError as e:
+        raise IndexError('caption refers to a video that is not in vis_ids: %s' % e)   # reference: gt_index[0] fails
+
+
+def t2v_ranks(S, owner):
+    """1-based rank of the ground-truth video of every text row, counted on the device."""
+    gt = torch.as_tensor(owner, dtype=torch.int32, device=S.device)
+    s_gt = ops.gather_gt(S, gt)
+    return ops.rank_count(S, gt, s_gt) + 1
+
+
+def t2v_metrics(S, owner):
+    """(r1, r5, r10, medr, meanr, mir, mAP) of predictor.py:232-246 (one GT per text => AP = 1/rank)."""
+    return ops.rank_metrics(t2v_ranks(S, owner).to(torch.int32))
+
+
+def v2t_positions(S, owner):
+    """For every text t: 1-based position of t in the descending column of its owner video."""
+    owner = np.asarray(owner, dtype=np.int64)
+    Nv = S.shape[1]
+    order = np.argsort(owner, kind='stable').astype(np.int32)
+    counts = np.bincount(owner, minlength=Nv)
+    off = np.zeros(Nv + 1, dtype=np.int32)
+    np.cumsum(counts, out=off[1:])
+    cnt = ops.v2t_count(S, torch.as_tensor(off, device=S.device), torch.as_tensor(order, device=S.device), int(counts.max()))
+    return cnt.cpu().numpy().astype(np.int64) + 1, order, off
+
+
+def v2t_metrics(S, owner):
+    """predictor.py:262-276: per video, positions of all its captions -> evaluation.eval arithmetic."""
+    pos, order, off = v2t_positions(S, owner)
+    Nv = S.shape[1]
+    if (np.diff(off) == 0).any():
+        raise IndexError('a video has no caption: the reference fails on rank[0] (evaluation.py:99)')
+    p = pos[order]                                   # grouped by video
+    grp = np.repeat(np.arange(Nv), np.diff(off))
+    # sort positions inside each group; equal scores among a video's own captions get consecutive places
+    key = np.lexsort((p, grp))
+    p, grp = p[key], grp[key]
+    start = off[:-1][grp]
+    within = np.arange(len(p)) - start               # 0-based index i of the GT inside its group
+    for _ in range(int(np.diff(off).max())):         # make ties strictly increasing
+        bump = (within > 0) & (p <= np.roll(p, 1))
+        if not bump.any():
+            break
+        p = np.where(bump, np.roll(p, 1) + 1, p)
+    first = p[off[:-1]]
+    ap = np.add.reduceat((within + 1.0) / p, off[:-1]) / np.diff(off)
+    return evaluation.eval_from_positions(first, ap)
+
+
+def retrieval_metrics(S, txt_ids, vis_ids):
+    """Both directions from a device score matrix, as get_predict_file reports them."""
+    if not isinstance(S, torch.Tensor):
+        S = torch.as_tensor(np.ascontiguousarray(S, dtype=np.float32), device='cuda')
+    owner = gt_columns(txt_ids, vis_ids)
+    return t2v_metrics(S, owner), v2t_metrics(S, owner)

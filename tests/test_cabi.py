@@ -1,0 +1,55 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/laff_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'laff_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(laff_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    for s in ('laff_ctx_create', 'laff_fc_act_bn', 'laff_fuse', 'laff_frame_fuse', 'laff_pack_rows', 'laff_sim_gemm',
+              'laff_rank_count', 'laff_v2t_count', 'laff_rank_metrics', 'laff_last_error'):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from laff_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from laff_amd.build import build_library
+        build_library(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(lib, s), 'liblaff_hip.so does not export %s' % s
+    assert lib.laff_abi_version() == _lib.ABI_VERSION
+
+
+def test_binding_covers_every_declared_symbol():
+    from laff_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    _lib.load()
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    from laff_amd import _lib
+    lib = _lib.load()
+    n = ctypes.c_size_t()
+    assert lib.laff_packed_bytes(10, 512, 3, ctypes.byref(n)) == 0 and n.value == 10 * 512 * 2 * 2
+    assert lib.laff_packed_bytes(10, 512, 99, ctypes.byref(n)) == -1
+    assert b'precision' in lib.laff_last_error()
+    assert lib.laff_fuse(None, None, 1, 1, 1, 4, None, None, None, 0, None, None) == -1
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+    from laff_amd import ops
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        ops.fc_act_bn(torch.zeros(4, 8), torch.zeros(16, 8))

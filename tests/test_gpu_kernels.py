@@ -1,0 +1,257 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against the CPU oracle and the golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import laff_oracle as O
+from util import maxdiff
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def rnd(seed):
+    return np.random.default_rng(seed)
+
+
+# ---------------------------------------------------------------------------------------------- a1
+@pytest.mark.parametrize('N,Dk,D', [(1, 4, 4), (33, 96, 512), (130, 1030, 260), (257, 2048, 384), (64, 512, 4096),
+                                    (70, 77, 130), (5, 3981, 200)])
+@pytest.mark.parametrize('act,bn', [('tanh', True), (None, False), ('relu', True), ('sigmoid', False)])
+def test_fc_act_bn_vs_oracle(N, Dk, D, act, bn):
+    from laff_amd import ops
+    g = rnd(N * 7 + Dk)
+    x = g.normal(0, 1, (N, Dk)).astype(np.float32)
+    W = (g.normal(0, 1, (D, Dk)) / np.sqrt(Dk)).astype(np.float32)
+    b = g.normal(0, 0.1, D).astype(np.float32)
+    scale = g.uniform(0.5, 1.5, D).astype(np.float32) if bn else None
+    shift = g.normal(0, 0.1, D).astype(np.float32) if bn else None
+    y = ops.fc_act_bn(dev(x), dev(W), dev(b), dev(scale) if bn else None, dev(shift) if bn else None, act)
+    ref = O.activation((x.astype(np.float64) @ W.astype(np.float64).T + b).astype(np.float32), act)
+    if bn:
+        ref = ref * scale + shift
+    assert maxdiff(y, ref) <= 2e-5     # fp32 fma-chain vs fp64-accumulated reference, |y| <= ~6
+
+
+def test_fc_act_bn_golden(golden):
+    from laff_amd import ops
+    g = golden('transform_net')
+    for c in g.json('cases'):
+        if not c['fc']:
+            continue
+        k = c['key']
+        sd = g.sub(k + '/sd/')
+        scale = shift = None
+        if c['batch_norm']:
+            scale = sd['bn1.weight'] / np.sqrt(sd['bn1.running_var'] + 1e-5)
+            shift = sd['bn1.bias'] - sd['bn1.running_mean'] * scale
+        y = ops.fc_act_bn(dev(g[k + '/x']), dev(sd['fc1.weight']), dev(sd['fc1.bias']),
+                          dev(scale) if scale is not None else None, dev(shift) if shift is not None else None,
+                          c['activation'])
+        assert maxdiff(y, g[k + '/y']) <= 2e-5
+
+
+def test_fc_strided_views():
+    """ld != width on every operand (row-slices of wider buffers)."""
+    from laff_amd import ops
+    g = rnd(5)
+    xb = dev(g.normal(0, 1, (40, 96)).astype(np.float32))
+    wb = dev(g.normal(0, 1, (50, 80)).astype(np.float32))
+    out = torch.zeros((40, 72), device=DEV)
+    ops.fc_act_bn(xb[:, :64], wb[:, :64], out=out[:, 8:58])
+    ref = xb[:, :64].double().cpu().numpy() @ wb[:, :64].double().cpu().numpy().T
+    assert maxdiff(out[:, 8:58], ref.astype(np.float32)) <= 2e-5
+    assert float(out[:, :8].abs().max()) == 0 and float(out[:, 58:].abs().max()) == 0
+
+
+# ---------------------------------------------------------------------------------------------- a5/a6
+def test_attention_1_golden(golden):
+    from laff_amd import ops
+    g = golden('attention_1')
+    for c in g.json('cases'):
+        k = c['key']
+        x = dev(g[k + '/x'] if c.get('own_x') else g['x'])
+        planes = [(x[:, l, :], False, None, None) for l in range(x.shape[1])]
+        flags = ops.attention_flags(c['with_ave'], c['mul'])
+        E, aw = ops.fuse(planes, 1, 512, dev(g[k + '/w']).view(1, 512), dev(g[k + '/b']).view(1),
+                         dev(np.float32(c['gw'])).view(1), flags, return_weights=True)
+        assert maxdiff(E[:, 0, :], g[k + '/out']) <= 2e-6
+        if k + '/weights' in g and not c['with_ave']:
+            assert maxdiff(aw[:, 0, :], g[k + '/weights']) <= 2e-6
+    x = dev(g['x'])
+    planes = [(x[:, l, :], False, None, None) for l in range(x.shape[1])]
+    E = ops.fuse(planes, 1, 512, None, None, None, ops.attention_flags(just_average=True))
+    assert maxdiff(E[:, 0, :], g['just_average/out']) <= 1e-6
+
+
+def test_multi_head_golden(golden):
+    from laff_amd import ops
+    g = golden('multi_head')
+    for c in g.json('cases'):
+        k = c['key']
+        sd = g.sub(k + '/sd/')
+        att = O.attention_from_sd(sd, '', c['H'], c['with_ave'], c['mul'], c['split_head'], c['l2norm_each_head'])
+        x = dev(g[k + '/x'])
+        planes = [(x[:, l, :], False, None, None) for l in range(x.shape[1])]
+        d = c['D'] // c['H'] if c['split_head'] else c['D']
+        flags = ops.attention_flags(c['with_ave'], c['mul'], c['l2norm_each_head'], c['split_head'])
+        E = ops.fuse(planes, c['H'], d, dev(att['w']), dev(att['b']), dev(att['gw']), flags)
+        assert maxdiff(E, g[k + '/out']) <= 2e-6, c
+
+
+@pytest.mark.parametrize('L', [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('H,d', [(8, 512), (1, 512), (2, 256), (4, 64), (1, 1024), (2, 2048)])
+def test_fuse_vs_oracle_with_tiled_planes(L, H, d):
+    """Mixed FC planes and tiled no-transform planes with folded BN (model/model.py:1801-1805,1822-1823)."""
+    from laff_amd import ops
+    g = rnd(100 * L + H + d)
+    N, D = 19, H * d
+    planes_np, planes = [], []
+    for l in range(L):
+        if l % 2 == 1:
+            x = g.normal(0, 1, (N, d)).astype(np.float32)
+            sc = g.uniform(0.5, 1.5, D).astype(np.float32)
+            sh = g.normal(0, 0.1, D).astype(np.float32)
+            planes_np.append(np.tile(x, (1, H)) * sc + sh)
+            planes.append((dev(x), True, dev(sc), dev(sh)))
+        else:
+            y = np.tanh(g.normal(0, 1, (N, D))).astype(np.float32)
+            planes_np.append(y)
+            planes.append((dev(y), False, None, None))
+    w = g.uniform(-1, 1, (H, d)).astype(np.float32) / np.sqrt(d)
+    b = g.normal(0, 0.3, H).astype(np.float32)
+    gw = g.uniform(0, 1, H).astype(np.float32)
+    for with_ave, mul in ((False, False), (True, True)):
+        ref = O.multi_head_attention(np.stack(planes_np, 1), w, b, gw, H, with_ave, mul)
+        E = ops.fuse(planes, H, d, dev(w), dev(b), dev(gw), ops.attention_flags(with_ave, mul))
+        assert maxdiff(E, ref) <= 3e-6
+
+
+# ---------------------------------------------------------------------------------------------- a7
+@pytest.mark.parametrize('flags_name', ['attention_noAveNoAverageMul', 'average_AverageMul_noAve',
+                                        'attention_noAverageMul_Ave', 'attention_averageMul'])
+@pytest.mark.parametrize('d', [512, 64, 1024])
+def test_frame_fuse_vs_oracle(flags_name, d):
+    from laff_amd import ops
+    with_ave, mul = O.FRAME_ATTENTION_FLAGS[flags_name]
+    g = rnd(len(flags_name) + d)
+    B, Fmax = 23, 17
+    lens = g.integers(1, Fmax + 1, B).astype(np.int32)
+    lens[0], lens[1] = Fmax, 1
+    frames = np.zeros((B, Fmax, d), np.float32)
+    for i in range(B):
+        frames[i, :lens[i]] = g.normal(0, 1, (lens[i], d))
+    w = (g.uniform(-1, 1, d) / np.sqrt(d)).astype(np.float32)
+    b, gw = np.float32(0.37), np.float32(0.7)
+    ref = O.frame_attention(frames, w, b, with_ave, mul, gw)
+    flags = ops.attention_flags(with_ave, mul)
+    out_masked = ops.frame_fuse(dev(frames), dev(lens, torch.int32), dev(w), dev(b).view(1), dev(gw).view(1), flags)
+    out_full = ops.frame_fuse(dev(frames), None, dev(w), dev(b).view(1), dev(gw).view(1), flags)
+    assert maxdiff(out_masked, ref) <= 2e-6
+    assert maxdiff(out_full, ref) <= 2e-6
+
+
+# ---------------------------------------------------------------------------------------------- a8-a11
+PREC_TOL = {'fp32': 2e-6, 'fp16x3': 2e-6, 'bf16x3': 5e-6, 'fp16': 1e-4, 'bf16': 2e-3}
+
+
+@pytest.mark.parametrize('precision', list(PREC_TOL))
+@pytest.mark.parametrize('Nt,Nv,H,d', [(41, 29, 1, 512), (300, 257, 8, 512), (129, 128, 2, 64), (1, 1, 1, 64)])
+def test_txt2vis_vs_oracle(precision, Nt, Nv, H, d):
+    from laff_amd import ops
+    g = rnd(Nt + Nv + H)
+    t = g.normal(0, 1, (Nt, H, d)).astype(np.float32)
+    v = g.normal(0, 2, (Nv, H, d)).astype(np.float32)
+    ref = O.txt2vis_matrix(t, v)
+    T = ops.pack_rows(dev(t), True, 1e-13, precision)
+    V = ops.pack_rows(dev(v), True, 1e-13, precision)
+    S = ops.sim_gemm(T, V, heads=H)
+    assert maxdiff(S, ref) <= PREC_TOL[precision]
+
+
+def test_txt2vis_golden(golden):
+    from laff_amd import loss, ops
+    g = golden('txt2vis')
+    assert maxdiff(loss.cosine_sim(dev(g['t2']), dev(g['v2']), 'fp16x3'), g['s2']) <= 2e-6
+    assert maxdiff(loss.cosine_sim(dev(g['t2']), dev(g['v2']), 'fp16'), g['s2']) <= 1e-4
+    assert maxdiff(loss.l2norm(dev(g['l2/x'])), g['l2/default']) <= 1e-6
+    for prec, tol in (('fp32', 2e-6), ('fp16', 1e-4)):
+        T = ops.pack_rows(dev(g['t3']), True, 1e-13, prec)
+        V = ops.pack_rows(dev(g['v3']), True, 1e-13, prec)
+        assert maxdiff(ops.sim_gemm(T, V, heads=8), g['s3']) <= tol
+    T = ops.pack_rows(dev(g['t3u']), True, 1e-13, 'fp32')
+    V = ops.pack_rows(dev(g['v3u']), True, 1e-13, 'fp32')
+    assert maxdiff(ops.sim_gemm(T, V, heads=4), g['s3u']) <= 2e-6
+
+
+def test_sim_gemm_is_transpose_detecting():
+    """Asymmetric operands: S[t, v] must pair text row t with video row v (guide rule 16)."""
+    from laff_amd import ops
+    Nt, Nv, K = 200, 136, 64
+    t = np.zeros((Nt, K), np.float32)
+    v = np.zeros((Nv, K), np.float32)
+    t[:, 0] = np.arange(Nt) + 1
+    v[:, 0] = 1.0 / (np.arange(Nv) + 1)
+    T = ops.pack_rows(dev(t), False, 0.0, 'fp32', 1.0)
+    V = ops.pack_rows(dev(v), False, 0.0, 'fp32', 1.0)
+    S = ops.sim_gemm(T, V)
+    ref = np.outer(t[:, 0], v[:, 0]).astype(np.float32)
+    assert maxdiff(S, ref) <= 1e-4 * 200
+
+
+# ---------------------------------------------------------------------------------------------- a12/a13
+def test_rank_kernels_golden(golden):
+    from laff_amd import predictor
+    g = golden('eval')
+    for c in g.json('cases'):
+        k = c['key']
+        t2v, v2t = predictor.retrieval_metrics(dev(g[k + '/S']), g.json(k + '/txt_ids'), g.json(k + '/vis_ids'))
+        np.testing.assert_allclose(t2v, g[k + '/t2v'], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(v2t, g[k + '/v2t'], rtol=0, atol=1e-12)
+
+
+def test_fused_rank_count_equals_unfused():
+    from laff_amd import ops
+    g = rnd(77)
+    Nt, Nv, K = 515, 391, 128
+    t = g.normal(0, 1, (Nt, K)).astype(np.float32)
+    v = g.normal(0, 1, (Nv, K)).astype(np.float32)
+    gt = (np.arange(Nt) % Nv).astype(np.int32)
+    T = ops.pack_rows(dev(t), True, 1e-13, 'fp16')
+    V = ops.pack_rows(dev(v), True, 1e-13, 'fp16')
+    S = ops.sim_gemm(T, V)
+    gtd = dev(gt, torch.int32)
+    s_gt = ops.gather_gt(S, gtd)
+    cnt_ref = ops.rank_count(S, gtd, s_gt)
+    cnt = torch.zeros(Nt, dtype=torch.int32, device=DEV)
+    S2 = ops.sim_gemm(T, V, gt_col=gtd, s_gt=s_gt, count=cnt)
+    assert torch.equal(S, S2)
+    assert torch.equal(cnt, cnt_ref)
+    cnt2 = torch.zeros(Nt, dtype=torch.int32, device=DEV)
+    ops.sim_gemm(T, V, want_scores=False, gt_col=gtd, s_gt=s_gt, count=cnt2)
+    assert torch.equal(cnt2, cnt_ref)
+    Sn = S.cpu().numpy()
+    ref = np.array([np.sum(np.delete(Sn[i], gt[i]) > Sn[i, gt[i]]) for i in range(Nt)])
+    assert np.array_equal(cnt_ref.cpu().numpy(), ref)
+
+
+def test_sharded_rank_count_sums_to_global():
+    """Column shards with col0 offsets + max/sum reductions reproduce the single-device ranks."""
+    from laff_amd import ops
+    g = rnd(78)
+    Nt, Nv = 300, 260
+    S = dev(g.normal(0, 1, (Nt, Nv)).astype(np.float32))
+    gt = dev((np.arange(Nt) * 7 % Nv).astype(np.int32), torch.int32)
+    full = ops.rank_count(S, gt, ops.gather_gt(S, gt))
+    bounds = [0, 65, 130, 195, 260]
+    parts = [S[:, a:b].contiguous() for a, b in zip(bounds[:-1], bounds[1:])]
+    s_gt = torch.stack([ops.gather_gt(p, gt, col0=a) for p, a in zip(parts, bounds[:-1])]).max(dim=0).values
+    total = torch.zeros(Nt, dtype=torch.int32, device=DEV)
+    for p, a in zip(parts, bounds[:-1]):
+        total += ops.rank_count(p, gt, s_gt, col0=a)
+    assert torch.equal(total, full)

@@ -1,0 +1,160 @@
+"""Model-level parity on a real MI355X: laff_amd towers / predict / metrics against the reference's golden outputs."""
+import numpy as np
+import pytest
+import torch
+
+from laff_amd.config import make_config
+from laff_amd.model import get_model
+from util import load_sd, maxdiff
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TXT_KEY = {'bow_feature': 'bow_encoding', 'w2v_feature': 'w2v_encoding', 'CLIP_encoding': 'CLIP_encoding'}
+
+
+def t(a):
+    return torch.from_numpy(np.array(a))     # CPU tensors: the towers move them, like the reference
+
+
+def test_laff_towers_golden(golden):
+    g = golden('laff_towers')
+    for c in g.json('cases'):
+        k = c['key']
+        cfg = make_config(c['vid_dims'], c['txt_dims'], c['D'], c['H'], 'LAFF', c['vis_no_transform'],
+                          c['txt_no_transform'], with_ave=c['with_ave'], mul=c['mul'], batch_norm=c['batch_norm'])
+        model = get_model('LAFF', DEV, cfg).eval()
+        res = load_sd(model, g.sub(k + '/sd/'))
+        assert not res.unexpected_keys and not res.missing_keys
+        vis_in = {n: t(g[k + '/vis/' + n]) for n in c['vid_dims']}
+        cap = {'caption': ['x'] * 24}
+        cap.update({TXT_KEY[n]: t(v) for n, v in g.sub(k + '/txt/').items()})
+        ve = model.vis_net(vis_in)
+        te = model.txt_net(cap)
+        assert tuple(ve.shape) == (24, c['H'], c['D'] // c['H'])
+        assert maxdiff(ve, g[k + '/vis_emb']) <= 5e-6
+        assert maxdiff(te, g[k + '/txt_emb']) <= 5e-6
+        assert maxdiff(model.get_txt2vis_matrix(te, ve, precision='fp16x3'), g[k + '/scores']) <= 5e-6
+        assert maxdiff(model.get_txt2vis_matrix(te, ve), g[k + '/scores']) <= 1e-4     # default fp16 operands
+        assert vis_in['X3D_L'].is_cuda       # in-place device move of the caller's dict, like the reference
+        assert maxdiff(model.encode_video({n: t(g[k + '/vis/' + n]) for n in c['vid_dims']}), g[k + '/vis_emb']) <= 5e-6
+
+
+def test_framelaff_golden(golden):
+    g = golden('framelaff')
+    for c in g.json('cases'):
+        k = c['key']
+        cfg = make_config(c['vid_dims'], {'bow': 20, 'CLIP': 512}, c['D'], c['H'], 'FrameLAFF',
+                          vis_no_transform=c['frame_feats'], txt_no_transform=['CLIP_encoder'],
+                          frame_feats={f: 512 for f in c['frame_feats']}, batch_norm=c['batch_norm'],
+                          vis_frame_attention=c['vis_frame_attention'], vis_frame_addFC=c['vis_frame_addFC'],
+                          frame_feat_with_video_feat=c['frame_feat_with_video_feat'])
+        model = get_model('FrameLAFF', DEV, cfg).eval()
+        res = load_sd(model, g.sub(k + '/sd/'))
+        assert not res.unexpected_keys
+        vis_in = {n: t(g[k + '/vis/' + n]) for n in c['vid_dims']}
+        frame_in = {'mask_tensor': t(g[k + '/mask']), c['frame_feats'][0]: t(g[k + '/frames'])}
+        ve = model.vis_net(vis_in, vis_frame_feat_dict_input=frame_in)
+        assert maxdiff(ve, g[k + '/vis_emb']) <= 5e-6, c
+        if k + '/frame_vec' in g:
+            assert maxdiff(vis_in[c['frame_feats'][0]], g[k + '/frame_vec']) <= 5e-6
+
+
+class _DS:
+    def __init__(self, n):
+        self.length = n
+
+    def __len__(self):
+        return self.length
+
+
+class VisLoader:
+    def __init__(self, feats, ids, bs):
+        self.feats, self.ids, self.batch_size, self.dataset = feats, ids, bs, _DS(len(ids))
+
+    def __len__(self):
+        return (len(self.ids) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for s in range(0, len(self.ids), self.batch_size):
+            e = min(len(self.ids), s + self.batch_size)
+            yield {'vis_feat_dict': {k: t(v[s:e]) for k, v in self.feats.items()}, 'idxs': list(range(s, e)),
+                   'vis_ids': tuple(self.ids[s:e]), 'vis_frame_feat_dict': {}, 'vis_origin_frame_tuple': (None,) * (e - s)}
+
+
+class TxtLoader:
+    def __init__(self, feats, ids, bs, perm):
+        self.feats, self.ids, self.batch_size, self.perm, self.dataset = feats, ids, bs, perm, _DS(len(ids))
+
+    def __len__(self):
+        return (len(self.ids) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for s in range(0, len(self.ids), self.batch_size):
+            order = self.perm[s:min(len(self.ids), s + self.batch_size)]
+            cap = {'caption': [self.ids[i] for i in order]}
+            cap.update({k: t(v[order]) for k, v in self.feats.items()})
+            yield cap, [int(i) for i in order], tuple(self.ids[i] for i in order)
+
+
+def test_predict_golden(golden):
+    """predict() end to end: same (scores, txt_ids, vis_ids) triple and the same 7+7 metrics as the reference."""
+    from laff_amd import predictor
+    g = golden('predict')
+    c = g.json('cfg')
+    cfg = make_config(c['vid_dims'], c['txt_dims'], c['D'], c['H'], 'LAFF', c['vis_no_transform'], c['txt_no_transform'])
+    model = get_model('LAFF', DEV, cfg).eval()
+    res = load_sd(model, g.sub('sd/'))
+    assert not res.unexpected_keys and not res.missing_keys
+    vis_ids, txt_ids = g.json('vis_ids'), g.json('txt_ids')
+    vl = VisLoader({n: g['vis/' + n] for n in c['vid_dims']}, vis_ids, c['bs'])
+    tl = TxtLoader({TXT_KEY[k]: v for k, v in g.sub('txt/').items()}, txt_ids, c['bs'], g['perm'])
+    model.sim_precision = 'fp16x3'
+    scores, out_txt, out_vis = model.predict(tl, vl, 'cosine', record_emb=True)
+    assert isinstance(scores, np.ndarray) and scores.dtype == np.float32
+    assert list(out_txt) == g.json('txt_ids_out') and list(out_vis) == g.json('vis_ids_out')
+    assert maxdiff(scores, g['scores']) <= 5e-6
+    assert maxdiff(model.video_all_embs, g['video_all_embs']) <= 5e-6
+    # cached video embeddings are reused for the next query set (record_emb, model/model.py:1026-1034)
+    before = model.video_all_embs.data_ptr()
+    model.sim_precision = None     # default fp16 operands: inside the 1e-4 contract
+    scores16, _, _ = model.predict(tl, vl, 'cosine', record_emb=True)
+    assert model.video_all_embs.data_ptr() == before
+    assert maxdiff(scores16, g['scores']) <= 1e-4
+    S, _, _ = model.retrieve(tl, vl, record_emb=True, precision='fp16x3')
+    t2v, v2t = predictor.retrieval_metrics(S, out_txt, out_vis)
+    np.testing.assert_allclose(t2v, g['t2v_metrics'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(v2t, g['v2t_metrics'], rtol=0, atol=1e-9)
+    S16, _, _ = model.retrieve(tl, vl, record_emb=True)
+    t2v16, v2t16 = predictor.retrieval_metrics(S16, out_txt, out_vis)
+    assert t2v16[:4] == tuple(g['t2v_metrics'][:4])      # R@1/5/10/MedR identical with fp16 operands
+    heads, _, _ = model.predict_each_head(tl, vl, 'cosine')
+    assert maxdiff(heads.mean(axis=0), g['scores']) <= 1e-4
+
+
+def test_single_head_model_runs_2d():
+    """'w2vpp_mutivis_attention' with plain Attention_1 blocks: 2-D embeddings, d = D = 2048 (streaming fuse kernel)."""
+    from oracle import laff_oracle as O
+    cfg = make_config({'a': 40, 'b': 24}, {'bow': 30, 'w2v': 20}, 2048, 1, 'w2vpp_mutivis_attention',
+                      txt_attention='attention_noAverageMul_Ave', vis_attention='average_AverageMul_noAve')
+    torch.manual_seed(3)
+    model = get_model('w2vpp_mutivis_attention', DEV, cfg).eval()
+    model.vis_net.attention_layer.embedding_common[0].bias.data.fill_(0.2)
+    model.txt_net.attention_layer.change_raw_global_emb_weight(0.6)
+    g = np.random.default_rng(4)
+    vis = {'a': g.normal(0, 1, (9, 40)).astype(np.float32), 'b': g.normal(0, 1, (9, 24)).astype(np.float32)}
+    ve = model.vis_net({k: t(v) for k, v in vis.items()})
+    assert tuple(ve.shape) == (9, 2048)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    specs = [O.feature_spec(sd, 'vis_net.VisMutiTransformNet.%s.' % n, vis[n], 'tanh', 1, False) for n in ('a', 'b')]
+    att = dict(kind='attention_1', w=sd['vis_net.attention_layer.embedding_common.0.weight'].reshape(-1),
+               b=float(sd['vis_net.attention_layer.embedding_common.0.bias']), with_ave=False, mul=True, gw=1.0)
+    assert maxdiff(ve, O.fuse_tower(specs, att, 1)) <= 5e-6
+    txt = {'bow_encoding': g.normal(0, 1, (7, 30)).astype(np.float32), 'w2v_encoding': g.normal(0, 1, (7, 20)).astype(np.float32)}
+    te = model.txt_net({'caption': [''] * 7, **{k: t(v) for k, v in txt.items()}})
+    specs = [O.feature_spec(sd, 'txt_net.transform_layer.%s_transform.' % e, txt[e.replace('encoder', 'encoding')], 'tanh', 1, False)
+             for e in ('bow_encoder', 'w2v_encoder')]
+    att = dict(kind='attention_1', w=sd['txt_net.attention_layer.embedding_common.0.weight'].reshape(-1),
+               b=float(sd['txt_net.attention_layer.embedding_common.0.bias']), with_ave=True, mul=False, gw=0.6)
+    assert maxdiff(te, O.fuse_tower(specs, att, 1)) <= 5e-6
+    S = model.get_txt2vis_matrix(te, ve, precision='fp32')
+    assert maxdiff(S, O.txt2vis_matrix(te.cpu().numpy(), ve.cpu().numpy())) <= 2e-6

@@ -1,0 +1,117 @@
+"""Host-side Python of laff_amd (no GPU): evaluation, BigFile, config/model construction, state_dict key parity."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from laff_amd import evaluation
+from laff_amd.bigfile import BigFile
+from laff_amd.config import make_config
+from laff_amd.model import get_model
+from laff_amd.predictor import gt_columns
+
+
+def test_eval_label_matrix(golden):
+    g = golden('eval')
+    np.testing.assert_allclose(evaluation.eval(g['label/matrix']), g['label/metrics'], rtol=0, atol=1e-12)
+    with pytest.raises(IndexError):
+        evaluation.eval(np.zeros((2, 3)))
+
+
+def test_eval_qry2retro(golden):
+    g = golden('eval')
+    np.testing.assert_allclose(evaluation.eval_qry2retro(g['q2r/S'], 1), g['q2r/metrics'], rtol=0, atol=1e-12)
+
+
+def test_eval_via_label_matrix_matches_predictor_fixture(golden):
+    """Build the label matrix the way predictor.py does (argsort) and feed our eval: same 7 numbers."""
+    g = golden('eval')
+    for c in g.json('cases'):
+        k = c['key']
+        S, gt = g[k + '/S'], g[k + '/gt']
+        inds = np.argsort(S, axis=1)[:, ::-1]
+        lab = (inds == gt[:, None]).astype(float)
+        np.testing.assert_allclose(evaluation.eval(lab), g[k + '/t2v'], rtol=0, atol=1e-12)
+
+
+def test_np_l2norm(golden):
+    g = golden('txt2vis')
+    np.testing.assert_allclose(evaluation.l2norm(g['l2/x']).astype(np.float32), g['l2/np'], rtol=0, atol=1e-7)
+
+
+def test_bigfile(golden):
+    exp = json.load(open(os.path.join(GOLDEN, 'bigfile_expect.json')))
+    for name, e in exp.items():
+        bf = BigFile(os.path.join(GOLDEN, name))
+        assert bf.shape() == e['shape'] and bf.names == e['names']
+        assert bf.ndims == e['ndims'] and bf.nr_of_images == e['nr_of_images']
+        names, vecs = bf.read(e['request'])
+        assert names == e['read_names']
+        np.testing.assert_array_equal(np.array(vecs, np.float32), np.array(e['read_vecs'], np.float32))
+        assert [list(x) for x in bf.read(['zzz'])] == e['read_empty']
+        names, vecs = bf.read([3, 1], isname=False)
+        assert names == e['by_index_names']
+        np.testing.assert_array_equal(np.array(vecs, np.float32), np.array(e['by_index_vecs'], np.float32))
+        np.testing.assert_array_equal(np.array(bf.read_one(e['names'][1]), np.float32), np.array(e['read_one'], np.float32))
+        with pytest.raises(IndexError):
+            bf.read_one('missing')
+        assert e['read_one_missing_error'] == 'IndexError'
+        m = bf.read_matrix([e['names'][2], e['names'][0], e['names'][2]])
+        np.testing.assert_array_equal(m, np.array(e['matrix'], np.float32)[[2, 0, 2]])
+
+
+def test_gt_columns():
+    owner = gt_columns(['b#0', 'a#1', 'b#enc#2'.replace('#enc', '')], ['a', 'b'])
+    assert owner.tolist() == [1, 0, 1]
+    with pytest.raises(IndexError):
+        gt_columns(['zz#0'], ['a'])
+    with pytest.raises(ValueError):
+        gt_columns(['a#0'], ['a', 'a'])
+
+
+def _model_keys(model):
+    return {k for k in model.state_dict().keys() if not k.startswith('txt_net.encoder.')}
+
+
+def test_state_dict_keys_match_reference_laff(golden):
+    g = golden('laff_towers')
+    for c in g.json('cases'):
+        cfg = make_config(c['vid_dims'], c['txt_dims'], c['D'], c['H'], 'LAFF', c['vis_no_transform'],
+                          c['txt_no_transform'], with_ave=c['with_ave'], mul=c['mul'], batch_norm=c['batch_norm'])
+        model = get_model('LAFF', 'cpu', cfg)
+        ref = {k for k in g.sub(c['key'] + '/sd/').keys()}
+        assert _model_keys(model) == ref
+        sd = g.sub(c['key'] + '/sd/')
+        for k, v in model.state_dict().items():
+            if k in sd:
+                assert tuple(v.shape) == tuple(sd[k].shape), k
+
+
+def test_state_dict_keys_match_reference_framelaff(golden):
+    g = golden('framelaff')
+    for c in g.json('cases'):
+        cfg = make_config(c['vid_dims'], {'bow': 20, 'CLIP': 512}, c['D'], c['H'], 'FrameLAFF',
+                          vis_no_transform=c['frame_feats'], txt_no_transform=['CLIP_encoder'],
+                          frame_feats={f: 512 for f in c['frame_feats']}, batch_norm=c['batch_norm'],
+                          vis_frame_attention=c['vis_frame_attention'], vis_frame_addFC=c['vis_frame_addFC'],
+                          frame_feat_with_video_feat=c['frame_feat_with_video_feat'])
+        model = get_model('FrameLAFF', 'cpu', cfg)
+        ref = set(g.sub(c['key'] + '/sd/').keys())
+        ours = {k for k in _model_keys(model) if k.startswith('vis_net.')}
+        assert ours == ref
+
+
+def test_training_mode_and_out_of_scope_models_fail_loudly():
+    cfg = make_config({'a': 16}, {'bow': 8}, 64, 1, txt_attention='attention_noAveNoAverageMul',
+                      vis_attention='attention_noAveNoAverageMul')
+    m = get_model('w2vpp_mutivis_attention', 'cpu', cfg)
+    with pytest.raises(NotImplementedError):
+        m(None)
+    with pytest.raises(NotImplementedError):
+        get_model('End2EndClip', 'cpu', cfg)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m.vis_net({'a': torch.zeros(2, 16)})
