@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- LAFF retrieval hot path on MI355X: text-video cosine pairs/s (+ R@1/5/10/MedR).
+
+    python bench.py [--gpus N --steps K --warmup W --workload c4_40kx10k --precision fp16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full pass of the hot path over the synthetic workload with every input already resident in HBM:
+8 FC projections (fp32 MFMA) -> 2 LAFF fusions -> operand packing -> text x video similarity GEMM writing the fp32
+score matrix -> ground-truth rank counts -> R@K / MedR / mAP on the host.  Default workload: BASELINE.json's headline
+shape, 40k texts x 10k videos x (4+4 features of 512-d), one head of d = 512 (`configs[3]`; it fits one GPU).
+With N > 1 the SAME total problem is sharded by video rows (strong scaling) with one RCCL all-gather of the text
+operand (laff_amd/dist.py).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0, 'bf16': 2500.0}
+
+
+class StageTimer:
+    """HIP events on torch's current stream == the stream liblaff_hip launches on (ops._context binds it)."""
+
+    def __init__(self):
+        self.events = []      # (name, event) ; name None = step start
+        self.enabled = True
+
+    def start(self):
+        if self.enabled:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.append((None, e))
+
+    def mark(self, name):
+        if self.enabled:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.append((name, e))
+
+    def totals(self):
+        """name -> (total ms, count) over all recorded steps."""
+        out = {}
+        prev = None
+        for name, e in self.events:
+            if name is not None and prev is not None:
+                ms = prev.elapsed_time(e)
+                t, c = out.get(name, (0.0, 0))
+                out[name] = (t + ms, c + 1)
+            prev = e
+        return out
+
+
+class LaunchProfiler:
+    """Per-launch HIP events (ops.profiler hook): begin/end are recorded on the stream the kernel is launched on."""
+
+    def __init__(self):
+        self.spans = []
+        self.enabled = False
+        self._open = None
+
+    def begin(self, name):
+        if self.enabled:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._open = e
+
+    def end(self, name):
+        if self.enabled:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.spans.append((name, self._open, e))
+
+    def totals(self):
+        out = {}
+        for name, a, b in self.spans:
+            t, c = out.get(name, (0.0, 0))
+            out[name] = (t + a.elapsed_time(b), c + 1)
+        return out
+
+
+def cpu_baseline(workload, sample_nt, sample_nv, heads, d, seed):
+    """The oracle (numpy restatement of the reference, `oracle/`) timed on this host's cores on a bounded sample of the
+    same workload, in the reference's own shape: batch-64 block loop with per-block re-normalisation
+    (model/model.py:1057-1077), then argsort-free count ranks.  kind = "port"."""
+    from laff_amd import synth
+    from oracle import laff_oracle as O
+    dev = torch.device('cuda:0')
+    model = synth.build_model(heads, d, dev, seed=seed)
+    vis, txt, gt, _ = synth.make_features(sample_nt, sample_nv, dev, seed=seed)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    vis_np, txt_np, gt_np = synth.to_numpy_dict(vis), synth.to_numpy_dict(txt), gt.cpu().numpy()
+    enc = {'rnn_encoder': 'rnn_encoding', 'bow_encoder': 'bow_encoding', 'w2v_encoder': 'w2v_encoding',
+           'CLIP_encoder': 'CLIP_encoding'}
+    names = list(model.txt_net.encoder_name_list)
+    del model, vis, txt
+    torch.cuda.empty_cache()
+    bs = 64
+    t0 = time.perf_counter()
+    att_v = O.attention_from_sd(sd, 'vis_net.attention_layer.', heads, False, False)
+    att_t = O.attention_from_sd(sd, 'txt_net.attention_layer.', heads, False, False)
+    vb = []
+    for s in range(0, sample_nv, bs):
+        specs = [O.feature_spec(sd, 'vis_net.VisMutiTransformNet.%s.' % n, vis_np[n][s:s + bs], 'tanh', heads, False)
+                 for n in synth.VID_FEATS]
+        vb.append((np.arange(s, min(sample_nv, s + bs)), O.fuse_tower(specs, att_v, heads)))
+    tb = []
+    for s in range(0, sample_nt, bs):
+        specs = [O.feature_spec(sd, 'txt_net.transform_layer.%s_transform.' % e, txt_np[enc[e]][s:s + bs], 'tanh', heads, False)
+                 for e in names]
+        tb.append((np.arange(s, min(sample_nt, s + bs)), O.fuse_tower(specs, att_t, heads)))
+    S = O.predict_blocked(tb, vb, sample_nt, sample_nv)
+    s_gt = S[np.arange(sample_nt), gt_np]
+    ranks = (S > s_gt[:, None]).sum(axis=1) + 1
+    metrics = O.eval_from_positions([[r] for r in ranks])
+    dt = time.perf_counter() - t0
+    return {'value': sample_nt * sample_nv / dt, 'unit': 'pairs/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': '%dx%d slice of the same synthetic workload, numpy oracle in the reference\'s batch-64 block-loop '
+                      'shape, %.1f s' % (sample_nt, sample_nv, dt),
+            'r1': metrics[0]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='c4_40kx10k')
+    ap.add_argument('--precision', default='fp16')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--seed', type=int, default=1237)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    dev = torch.device('cuda', local_rank)
+
+    from laff_amd import synth
+    from laff_amd.dist import HipBackend, evaluate_sharded, shard_bounds
+    Nt, Nv, heads, d, frames = synth.WORKLOADS[args.workload]
+    model = synth.build_model(heads, d, dev, frames=frames, seed=args.seed)
+    vis, txt, gt, lens = synth.make_features(Nt, Nv, dev, frames=frames, seed=args.seed)
+    t0, t1 = shard_bounds(Nt, world, rank)
+    v0, v1 = shard_bounds(Nv, world, rank)
+    vis_l = {k: v[v0:v1].contiguous() for k, v in vis.items()}
+    txt_l = {k: v[t0:t1].contiguous() for k, v in txt.items()}
+    del vis, txt
+    backend = HipBackend(model, args.precision)
+    timer = StageTimer()
+    from laff_amd import ops
+    prof = LaunchProfiler()
+    ops.profiler = prof
+
+    def step(timed):
+        timer.enabled = timed
+        prof.enabled = timed
+        timer.start()
+        return evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer)
+
+    for _ in range(args.warmup):
+        res = step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        pairs = float(Nt) * Nv
+        stages = {k: t / c for k, (t, c) in timer.totals().items()}     # ms per step per stage (this rank)
+        # ---- roofline of the dominant kernel: ALGORITHMIC work (SURVEY.md section 8d / DESIGN.md) / measured launch time
+        K = heads * d
+        nvl, ntl = v1 - v0, t1 - t0
+        feat, L = 512, 4
+        launches = {k: (t / args.steps, c // args.steps) for k, (t, c) in prof.totals().items()}   # ms per step, launches per step
+        x3 = 3 if args.precision.endswith('x3') else 1
+        work = {   # entry point -> (bound, algorithmic units per step on this rank, peak, unit scale)
+            'fc_act_bn': ('mfma', 2.0 * feat * K * L * (ntl + nvl), MFMA_PEAK_TFLOPS['f32'], 1e12, 'TFLOP/s'),
+            'fuse': ('hbm', 4.0 * (ntl + nvl) * K * (L + 1), HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'pack_rows': ('hbm', (4.0 + 2.0 * (2 if x3 == 3 else 1)) * (ntl + nvl) * K, HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'rank_count': ('hbm', 4.0 * Nt * nvl, HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'gather_gt': ('hbm', 8.0 * Nt, HBM_PEAK_GBS, 1e9, 'GB/s'),
+        }
+        sim_bytes = 4.0 * Nt * nvl + 2.0 * (Nt + nvl) * K                  # fp32 S written once + 16-bit operands read once
+        sim_flops = 2.0 * K * Nt * nvl * x3
+        sim_ms = launches.get('sim_gemm', (0.0, 0))[0]
+        if sim_ms > 0:
+            hbm_frac = sim_bytes / (sim_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            mfma_frac = sim_flops / (sim_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS['f16']
+            if mfma_frac >= hbm_frac:
+                work['sim_gemm'] = ('mfma', sim_flops, MFMA_PEAK_TFLOPS['f16'], 1e12, 'TFLOP/s')
+            else:
+                work['sim_gemm'] = ('hbm', sim_bytes, HBM_PEAK_GBS, 1e9, 'GB/s')
+        dom = max(launches, key=lambda k: launches[k][0]) if launches else None
+        roof = {'bound': None, 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None}
+        per_kernel = {}
+        for k, (ms, n) in launches.items():
+            if k in work and ms > 0:
+                bound, units, peak, scale, unit = work[k]
+                ach = units / (ms * 1e-3) / scale
+                per_kernel[k] = {'ms_per_step': round(ms, 4), 'launches_per_step': n, 'bound': bound, 'achieved': round(ach, 2),
+                                 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4)}
+        if dom in per_kernel:
+            pk = per_kernel[dom]
+            roof = {'kernel': 'laff_' + dom, 'bound': pk['bound'], 'achieved': pk['achieved'], 'peak': pk['peak'], 'unit': pk['unit'],
+                    'frac': pk['frac'], 'traffic': None, 'launches_per_step': pk['launches_per_step'],
+                    'avg_launch_ms': round(pk['ms_per_step'] / max(1, pk['launches_per_step']), 5)}
+        m = res['metrics']
+        line = {
+            'metric': 'text-video cosine pairs/sec', 'value': pairs / elapsed * args.steps, 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32 towers + %s similarity' % args.precision,
+            'data': 'synthetic',
+            'config': {'workload': '%s: %d texts x %d videos, 4+4 features of 512-d, %d head(s) x d=%d' % (args.workload, Nt, Nv, heads, d),
+                       'parallelism': 'video-row shards x%d, all-gather of text operand' % world if world > 1 else 'single GPU',
+                       'scores': 'fp32 S materialised in HBM'},
+            'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6]},
+            'stages_ms': {k: round(v, 4) for k, v in stages.items()},
+            'kernels': per_kernel,
+            'roofline': roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sn, sv = (8000, 2000) if Nt >= 8000 and Nv >= 2000 else (Nt, Nv)
+            line['cpu_baseline'] = cpu_baseline(args.workload, sn, sv, heads, d, args.seed)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

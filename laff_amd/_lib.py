@@ -46,6 +46,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError('liblaff_hip.so is missing (%s): build it with `python -m laff_amd.build`; '
                                'laff_amd has no CPU fallback' % LIB_PATH)
+        # torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  It must be in the process BEFORE
+        # liblaff_hip.so is loaded so that both resolve to ONE HIP runtime (shared streams / allocations); loaded
+        # the other way round the second runtime sees no device.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is not exported

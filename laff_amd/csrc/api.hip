@@ -186,10 +186,12 @@ int laff_pack_rows(laff_ctx* ctx, const float* E, int N, int H, int d, int lde, 
                    int precision, void* out) {
     CHECK_CTX(ctx);
     if (!E || !out) return fail(LAFF_E_ARG, "laff_pack_rows: null E/out");
-    if (N < 0 || H < 1 || d < 4 || (d & 3) || lde < H * d || (lde & 3))
+    if (N < 0 || H < 1 || d < 1 || lde < H * d)
         return fail(LAFF_E_SHAPE, "laff_pack_rows: bad shape N=%d H=%d d=%d lde=%d", N, H, d, lde);
     if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "laff_pack_rows: bad precision %d", precision);
-    if (!aligned16(E) || !aligned16(out)) return fail(LAFF_E_ALIGN, "laff_pack_rows: 16-byte alignment");
+    const bool vec = !(d & 3) && !(lde & 3) && aligned16(E) && aligned16(out);
+    if (!vec && precision != LAFF_PREC_FP32)
+        return fail(LAFF_E_ALIGN, "laff_pack_rows: 16-bit output needs d%%4==0, lde%%4==0 and 16-byte aligned buffers (d=%d lde=%d)", d, lde);
     if (N == 0) return LAFF_OK;
     DeviceGuard g(ctx->device);
     HIP_TRY(laff::launch_pack_rows(E, N, H, d, lde, normalize, eps, prescale, precision, out, ctx->stream));
@@ -286,7 +288,7 @@ int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, double out7[7]) {
         const int lo = *std::max_element(s.begin(), s.begin() + mid);
         med = 0.5 * (med + lo);
     }
-    out7[0] = 100.0 * c1 / Nq; out7[1] = 100.0 * c5 / Nq; out7[2] = 100.0 * c10 / Nq;
+    out7[0] = 100.0 * (c1 / Nq); out7[1] = 100.0 * (c5 / Nq); out7[2] = 100.0 * (c10 / Nq);   // numpy: 100.0 * mean
     out7[3] = std::floor(med); out7[4] = sum / Nq; out7[5] = isum / Nq; out7[6] = isum / Nq;
     return LAFF_OK;
 }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
     for (int j = 0; j < NCH; ++j) {
         const int col = j * 256 + lane * 4;
         const bool ok = col < d;
-        wv[j] = ok ? *(const float4*)(a.w + (long)h * d + col) : make_float4(0, 0, 0, 0);
+        wv[j] = (ok && a.w) ? *(const float4*)(a.w + (long)h * d + col) : make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int l = 0; l < L; ++l) x[l][j] = ok ? load_plane(a, l, n, h, col) : make_float4(0, 0, 0, 0);
     }
@@ -401,6 +401,18 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
     const float* src = E + n * lde + (long)h * d;
     const long K = (long)H * d;
     float mult = prescale;
+    if constexpr (PREC == LAFF_PREC_FP32) {
+        // generic (unaligned / d % 4 != 0) rows: scalar accesses, fp32 output only
+        if ((d & 3) || (lde & 3) || ((uintptr_t)E & 15) || ((uintptr_t)out & 15)) {
+            if (normalize) {
+                float ss = 0.f;
+                for (int col = lane; col < d; col += 64) ss += src[col] * src[col];
+                mult = prescale / (sqrtf(wave_sum(ss)) + eps + 1e-14f);
+            }
+            for (int col = lane; col < d; col += 64) ((float*)out)[n * K + (long)h * d + col] = src[col] * mult;
+            return;
+        }
+    }
     if (normalize) {
         float ss = 0.f;
         for (int col = lane * 4; col < d; col += 256) {

@@ -1,0 +1,124 @@
+"""Multi-GPU decomposition of the hot path (one process per GPU, torch.distributed; backend 'nccl' is RCCL over xGMI).
+
+The reference has no parallelism of any kind; this is the one data-parallel decomposition the
+path admits:
+
+  * video rows are split contiguously: rank g owns videos [v0, v1) end to end (features -> embeddings -> its
+    column block S[:, v0:v1] of the score matrix);
+  * text rows are split the same way for the embedding stage only, then ONE all-gather of the text GEMM operand
+    (Nt x K 16-bit) gives every rank all texts; it is issued asynchronously and overlaps the video tower;
+  * ranks: s_gt[t] comes from the rank that owns gt(t) -> all-reduce(MAX) of Nt floats; every rank counts the
+    better-scoring videos of its block -> all-reduce(SUM) of Nt int32.  No other collective; S is never gathered.
+
+`compute` is the per-rank kernel backend (HipBackend below; the gloo/CPU tests inject an oracle-backed stand-in),
+so the orchestration is exercised without a GPU.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous, balanced [lo, hi) -- the first n % world ranks get one extra row."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+class HipBackend:
+    """Per-rank compute on liblaff_hip.so."""
+
+    def __init__(self, model, precision='fp16'):
+        self.model, self.precision = model, precision
+
+    def embed_text(self, txt_feats):
+        cap = dict(txt_feats)
+        cap.setdefault('caption', None)
+        return self.model.txt_net(cap)
+
+    def embed_video(self, vis_feats):
+        vis = dict(vis_feats)
+        frame_dict = {}
+        if 'mask_tensor' in vis:
+            frame_dict, vis = vis, {}
+        return self.model.vis_net(vis, vis_frame_feat_dict_input=frame_dict)
+
+    def pack(self, E):
+        return ops.pack_rows(E, True, 1e-13, self.precision)
+
+    def operand_from_gathered(self, bufs, rows, K, like):
+        """Concatenated single-plane operand buffers of all ranks -> one Packed operand."""
+        return ops.Packed(bufs, rows, K, like.precision, like.prescale)
+
+    def sim(self, T, V, heads):
+        return ops.sim_gemm(T, V, heads=heads)
+
+    def gather_gt(self, S, gt, col0):
+        return ops.gather_gt(S, gt, col0)
+
+    def rank_count(self, S, gt, s_gt, col0):
+        return ops.rank_count(S, gt, s_gt, col0)
+
+    def metrics(self, ranks):
+        return ops.rank_metrics(ranks)
+
+
+def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
+                     timer=None):
+    """One pass of the hot path on this rank's shards.  gt: (Nt,) int32 GLOBAL video column of every text (replicated).
+
+    Returns dict(S_local (Nt, v1-v0), col0, ranks (Nt,), metrics)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    v0, v1 = shard_bounds(Nv, world, rank)
+    mark = timer.mark if timer is not None else (lambda name: None)
+    with torch.no_grad():
+        txt_emb = compute.embed_text(txt_feats_local)
+        mark('txt_tower')
+        T_local = compute.pack(txt_emb)
+        mark('pack')
+        work = None
+        if world > 1:
+            if T_local.precision in ('fp16', 'bf16'):
+                sizes = [shard_bounds(Nt, world, r) for r in range(world)]
+                nmax = max(hi - lo for lo, hi in sizes)
+                row_bytes = T_local.K * 2
+                send = T_local.buf[:T_local.N * row_bytes]
+                if T_local.N != nmax:       # equal-sized contributions for all_gather_into_tensor
+                    pad = torch.zeros(nmax * row_bytes, dtype=torch.uint8, device=send.device)
+                    pad[:send.numel()] = send
+                    send = pad
+                gathered = torch.empty(world * nmax * row_bytes, dtype=torch.uint8, device=send.device)
+                work = dist.all_gather_into_tensor(gathered, send.contiguous(), group=group, async_op=True)
+            else:
+                raise NotImplementedError("sharded evaluation gathers a single-plane 16-bit operand; precision '%s' "
+                                          "is single-GPU only for now" % T_local.precision)
+        vis_emb = compute.embed_video(vis_feats_local)
+        mark('vis_tower')
+        V_local = compute.pack(vis_emb)
+        mark('pack')
+        if world > 1:
+            work.wait()
+            if all(hi - lo == nmax for lo, hi in sizes):
+                T_all = compute.operand_from_gathered(gathered, Nt, T_local.K, T_local)
+            else:
+                parts = [gathered[r * nmax * row_bytes: r * nmax * row_bytes + (hi - lo) * row_bytes]
+                         for r, (lo, hi) in enumerate(sizes)]
+                T_all = compute.operand_from_gathered(torch.cat(parts), Nt, T_local.K, T_local)
+            mark('all_gather_wait')
+        else:
+            T_all = T_local
+        S_local = compute.sim(T_all, V_local, heads)
+        mark('sim_gemm')
+        s_gt = compute.gather_gt(S_local, gt, v0)
+        if world > 1:
+            dist.all_reduce(s_gt, op=dist.ReduceOp.MAX, group=group)
+        count = compute.rank_count(S_local, gt, s_gt, v0)
+        if world > 1:
+            dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
+        ranks = count + 1
+        mark('rank')
+        metrics = compute.metrics(ranks) if want_metrics else None
+        mark('metrics')
+    return {'S_local': S_local, 'col0': v0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb}

@@ -17,6 +17,18 @@ __all__ = ['fc_act_bn', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_g
 
 _ctx = {}
 
+#: optional per-launch profiler (bench.py): object with begin(name) / end(name), called on the launching stream
+profiler = None
+
+
+def _call(name, fn, *args):
+    if profiler is None:
+        check(fn(*args))
+    else:
+        profiler.begin(name)
+        check(fn(*args))
+        profiler.end(name)
+
 
 def _context(device):
     """One laff_ctx per device ordinal, re-bound to torch's current stream at every call."""
@@ -74,8 +86,8 @@ def fc_act_bn(x, weight, bias=None, bn_scale=None, bn_shift=None, activation=Non
         out = torch.empty((N, D), device=x.device, dtype=torch.float32)
     y, ldy = _rows(out, 'out')
     lib, h = _context(x.device)
-    check(lib.laff_fc_act_bn(h, _ptr(x), N, Dk, ldx, _ptr(w), ldw, _ptr(bias), _ptr(bn_scale), _ptr(bn_shift), D,
-                             ACT[activation], _ptr(y), ldy))
+    _call('fc_act_bn', lib.laff_fc_act_bn, h, _ptr(x), N, Dk, ldx, _ptr(w), ldw, _ptr(bias), _ptr(bn_scale), _ptr(bn_shift), D,
+                             ACT[activation], _ptr(y), ldy)
     return out
 
 
@@ -105,7 +117,7 @@ def fuse(planes, H, d, w, b, gw, flags, return_weights=False):
         if t is not None:
             _dev(t, nm)
     lib, h = _context(dev)
-    check(lib.laff_fuse(h, arr, L, N, H, d, _ptr(w), _ptr(b), _ptr(gw), flags, _ptr(E), _ptr(aw)))
+    _call('fuse', lib.laff_fuse, h, arr, L, N, H, d, _ptr(w), _ptr(b), _ptr(gw), flags, _ptr(E), _ptr(aw))
     return (E, aw) if return_weights else E
 
 
@@ -121,8 +133,8 @@ def frame_fuse(frames, lens, w, b, gw, flags):
             raise ValueError('lens must have %d entries' % B)
     V = torch.empty((B, d), device=frames.device, dtype=torch.float32)
     lib, h = _context(frames.device)
-    check(lib.laff_frame_fuse(h, _ptr(frames), _ptr(lens), B, Fmax, d, _ptr(_dev(w, 'w')), _ptr(_dev(b, 'b')),
-                              _ptr(gw), flags, _ptr(V)))
+    _call('frame_fuse', lib.laff_frame_fuse, h, _ptr(frames), _ptr(lens), B, Fmax, d, _ptr(_dev(w, 'w')), _ptr(_dev(b, 'b')),
+                              _ptr(gw), flags, _ptr(V))
     return V
 
 
@@ -153,7 +165,7 @@ def pack_rows(E, normalize=True, eps=1e-13, precision='fp16', prescale=None):
     nbytes = C.c_size_t()
     check(lib.laff_packed_bytes(N, H * d, PREC[precision], C.byref(nbytes)))
     buf = torch.empty((max(nbytes.value, 16),), device=E.device, dtype=torch.uint8)
-    check(lib.laff_pack_rows(h, _ptr(E), N, H, d, lde, 1 if normalize else 0, eps, prescale, PREC[precision], _ptr(buf)))
+    _call('pack_rows', lib.laff_pack_rows, h, _ptr(E), N, H, d, lde, 1 if normalize else 0, eps, prescale, PREC[precision], _ptr(buf))
     return Packed(buf, N, H * d, precision, prescale)
 
 
@@ -175,8 +187,8 @@ def sim_gemm(T, V, heads=1, out=None, want_scores=True, gt_col=None, s_gt=None, 
         _dev(count, 'count', torch.int32)
     scale = 1.0 / (heads * T.prescale * V.prescale)
     lib, h = _context(dev)
-    check(lib.laff_sim_gemm(h, _ptr(T.buf), _ptr(V.buf), T.N, V.N, T.K, scale, PREC[T.precision], _ptr(S), lds,
-                            _ptr(gt_col), col0, _ptr(s_gt), _ptr(count)))
+    _call('sim_gemm', lib.laff_sim_gemm, h, _ptr(T.buf), _ptr(V.buf), T.N, V.N, T.K, scale, PREC[T.precision], _ptr(S), lds,
+                            _ptr(gt_col), col0, _ptr(s_gt), _ptr(count))
     return S
 
 
@@ -185,7 +197,7 @@ def gather_gt(S, gt_col, col0=0):
     _dev(gt_col, 'gt_col', torch.int32)
     out = torch.empty((S.shape[0],), device=S.device, dtype=torch.float32)
     lib, h = _context(S.device)
-    check(lib.laff_gather_gt(h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(gt_col), col0, _ptr(out)))
+    _call('gather_gt', lib.laff_gather_gt, h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(gt_col), col0, _ptr(out))
     return out
 
 
@@ -198,8 +210,8 @@ def rank_count(S, gt_col, s_gt, col0=0, count=None):
         count = torch.empty((S.shape[0],), device=S.device, dtype=torch.int32)
     _dev(count, 'count', torch.int32)
     lib, h = _context(S.device)
-    check(lib.laff_rank_count(h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(gt_col), col0, _ptr(s_gt), _ptr(count),
-                              1 if acc else 0))
+    _call('rank_count', lib.laff_rank_count, h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(gt_col), col0, _ptr(s_gt), _ptr(count),
+                              1 if acc else 0)
     return count
 
 
@@ -209,8 +221,8 @@ def v2t_count(S, grp_off, grp_idx, max_group):
     _dev(grp_idx, 'grp_idx', torch.int32)
     count = torch.zeros((S.shape[0],), device=S.device, dtype=torch.int32)
     lib, h = _context(S.device)
-    check(lib.laff_v2t_count(h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(grp_off), _ptr(grp_idx), int(max_group),
-                             _ptr(count)))
+    _call('v2t_count', lib.laff_v2t_count, h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(grp_off), _ptr(grp_idx), int(max_group),
+                             _ptr(count))
     return count
 
 

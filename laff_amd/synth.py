@@ -39,6 +39,15 @@ def build_model(heads, d, device, frames=0, feat_dim=512, seed=1234):
         name = 'LAFF'
     torch.manual_seed(seed)
     model = get_model(name, device, cfg).eval()
+    if not frames:
+        # Random-init towers put text and video in unrelated spaces (chance-level recall).  Tie the text tower to the
+        # video tower (feature k <-> feature k, same FC and attention parameters) so that the planted latent survives
+        # and R@K / MedR are informative about the arithmetic; the architecture and the work per pair are unchanged.
+        vis_mods = [getattr(model.vis_net.VisMutiTransformNet, n) for n in VID_FEATS]
+        txt_mods = [getattr(model.txt_net.transform_layer, e + '_transform') for e in model.txt_net.encoder_name_list]
+        for tm, vm in zip(txt_mods, vis_mods):
+            tm.load_state_dict(vm.state_dict())
+        model.txt_net.attention_layer.load_state_dict(model.vis_net.attention_layer.state_dict())
     g = torch.Generator(device='cpu').manual_seed(seed + 1)
     for m in model.modules():
         if isinstance(m, nn.BatchNorm1d):
@@ -73,8 +82,16 @@ def make_features(Nt, Nv, device, frames=0, feat_dim=512, seed=1234, noise=0.5):
         for n in VID_FEATS:
             P = randn(LATENT, feat_dim) / LATENT ** 0.5
             vis[n] = zv @ P + noise * randn(Nv, feat_dim)
-    for n in TXT_FEATS:
-        P = randn(LATENT, feat_dim) / LATENT ** 0.5
+    Ps = []
+    if not frames:
+        g2 = torch.Generator(device=device).manual_seed(seed)      # replay the video projections P_k
+        torch.randn(Nv, LATENT, generator=g2, device=device)
+        for n in VID_FEATS:
+            Ps.append(torch.randn(LATENT, feat_dim, generator=g2, device=device) / LATENT ** 0.5)
+            torch.randn(Nv, feat_dim, generator=g2, device=device)
+    # text feature k of the tower (encoder order rnn, bow, w2v, CLIP) shares the projection of video feature k
+    for i, n in enumerate(('rnn', 'bow', 'w2v', 'CLIP')):
+        P = Ps[i] if Ps else randn(LATENT, feat_dim) / LATENT ** 0.5
         txt[TXT_KEY[n]] = zt @ P + noise * randn(Nt, feat_dim)
     return vis, txt, gt.to(torch.int32), lens
 
