@@ -209,6 +209,7 @@ def main():
             'pack_rows': ('hbm', (4.0 + 2.0 * (2 if x3 == 3 else 1)) * (ntl + nvl) * K, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'rank_count': ('hbm', 4.0 * Nt * nvl, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'gather_gt': ('hbm', 8.0 * Nt, HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'row_dot_gt': ('hbm', 2.0 * 2 * Nt * K, HBM_PEAK_GBS, 1e9, 'GB/s'),
         }
         sim_bytes = 4.0 * Nt * nvl + 2.0 * (Nt + nvl) * K                  # fp32 S written once + 16-bit operands read once
         sim_flops = 2.0 * K * Nt * nvl * x3

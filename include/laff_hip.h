@@ -77,6 +77,17 @@ int laff_fc_act_bn(laff_ctx* ctx, const float* X, int N, int Dk, int ldx, const 
                    const float* bias, const float* bn_scale, const float* bn_shift, int D, int act,
                    float* Y, int ldy);
 
+/* The same projection for up to 8 independent features in ONE launch (a3: the per-feature Python loop of
+ * VisMutiTransformNet.forward, model/model.py:1807-1827, and the text-side loop :1673-1681). */
+typedef struct {
+    const float* X; int N, Dk, ldx;
+    const float* W; int ldw;
+    const float* bias; const float* bn_scale; const float* bn_shift;
+    int D, act;
+    float* Y; int ldy;
+} laff_fc_problem;
+int laff_fc_act_bn_grouped(laff_ctx* ctx, const laff_fc_problem* problems /*host array*/, int count);
+
 /* ---- a2-a6: stack + Multi_head_MyApply_Attention / Attention_1 / JustAverage ----------------------------
  * (model/model.py:1858-1876, :1663-1705; model/Attention.py:508-531, :78-105)
  * One feature plane per fused feature; nothing is stacked or tiled in memory.
@@ -123,6 +134,13 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
                   int precision, float* S, int lds, const int* gt_col, int col0, const float* s_gt,
                   int* count);
 
+/* Ground-truth pre-pass for the fused count: s_gt[t] = scale * <T[t], V[gt_col[t]-col0]> on the packed operands
+ * (fp32 accumulation of the same 16-bit products), -inf when that column is outside [0,Nv).  When laff_sim_gemm is
+ * then called with gt_col/s_gt it writes exactly this value at S[t, gt] so counts and S stay consistent.
+ * 16-bit precisions only. */
+int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
+                    const int* gt_col, int col0, float* s_gt);
+
 /* s_gt[t] = S[t, gt_col[t]-col0] if that column is in [0,Nv) else -inf  (shard-local ground-truth score) */
 int laff_gather_gt(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0,
                    float* s_gt);
@@ -136,7 +154,8 @@ int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const
                    const int* grp_idx, int max_group, int* count);
 
 /* ---- a13: evaluation.eval (evaluation.py:92-109) for single-GT rows ---------------------------------------
- * rank1[Nq] device int32, 1-based.  out7 (host) = r1, r5, r10, medr, meanr, mir, mAP.  Synchronises the stream. */
+ * rank1[Nq] device int32, 1-based.  out7 (host) = r1, r5, r10, medr, meanr, mir, mAP.  Reduced on the device
+ * (one small kernel), 56 bytes copied back; synchronises the stream. */
 int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, double out7[7]);
 
 #ifdef __cplusplus

@@ -16,6 +16,12 @@ class Plane(C.Structure):
     _fields_ = [('src', C.c_void_p), ('ld', C.c_int), ('tile', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p)]
 
 
+class FcProblem(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('N', C.c_int), ('Dk', C.c_int), ('ldx', C.c_int), ('W', C.c_void_p), ('ldw', C.c_int),
+                ('bias', C.c_void_p), ('bn_scale', C.c_void_p), ('bn_shift', C.c_void_p), ('D', C.c_int), ('act', C.c_int),
+                ('Y', C.c_void_p), ('ldy', C.c_int)]
+
+
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     'laff_abi_version': (C.c_int, []),
@@ -25,11 +31,13 @@ SIGNATURES = {
     'laff_ctx_destroy': (C.c_int, [_P]),
     'laff_device_info': (C.c_int, [_P, C.POINTER(_I)]),
     'laff_fc_act_bn': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I]),
+    'laff_fc_act_bn_grouped': (C.c_int, [_P, C.POINTER(FcProblem), _I]),
     'laff_fuse': (C.c_int, [_P, C.POINTER(Plane), _I, _I, _I, _I, _P, _P, _P, C.c_uint, _P, _P]),
     'laff_frame_fuse': (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, C.c_uint, _P]),
     'laff_packed_bytes': (C.c_int, [_I, _I, _I, C.POINTER(C.c_size_t)]),
     'laff_pack_rows': (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
     'laff_sim_gemm': (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P]),
+    'laff_row_dot_gt': (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P]),
     'laff_gather_gt': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P]),
     'laff_rank_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I]),
     'laff_v2t_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _I, _P]),

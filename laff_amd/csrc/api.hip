@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,6 +15,8 @@
 struct laff_ctx {
     int device;
     hipStream_t stream;
+    double* d_metrics = nullptr;   // 7 doubles + 1 int flag (device)
+    double* h_metrics = nullptr;   // pinned host mirror
 };
 
 namespace {
@@ -70,6 +73,7 @@ const char* laff_last_error(void) { return g_err.c_str(); }
 
 int laff_ctx_create(int device, void* hip_stream, laff_ctx** out) {
     if (!out) return fail(LAFF_E_ARG, "laff_ctx_create: null out");
+    if (const char* e = getenv("LAFF_GEMM_VARIANT")) laff::g_gemm_variant = atoi(e);
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(LAFF_E_ARG, "laff_ctx_create: device %d out of range (%d devices)", device, n);
@@ -92,6 +96,10 @@ int laff_ctx_set_stream(laff_ctx* ctx, void* hip_stream) {
 }
 
 int laff_ctx_destroy(laff_ctx* ctx) {
+    if (ctx) {
+        if (ctx->d_metrics) (void)hipFree(ctx->d_metrics);
+        if (ctx->h_metrics) (void)hipHostFree(ctx->h_metrics);
+    }
     delete ctx;
     return LAFF_OK;
 }
@@ -108,23 +116,56 @@ int laff_device_info(laff_ctx* ctx, int out[4]) {
     return LAFF_OK;
 }
 
+static int fc_problem_args(const laff_fc_problem& q, laff::GemmArgs& a, bool& glds, const char* who) {
+    if (!q.X || !q.W || !q.Y) return fail(LAFF_E_ARG, "%s: null X/W/Y", who);
+    if (q.N < 0 || q.Dk < 1 || q.D < 1 || q.ldx < q.Dk || q.ldw < q.Dk || q.ldy < q.D)
+        return fail(LAFF_E_SHAPE, "%s: bad shape N=%d Dk=%d D=%d ldx=%d ldw=%d ldy=%d", who, q.N, q.Dk, q.D, q.ldx, q.ldw, q.ldy);
+    if (q.act < LAFF_ACT_NONE || q.act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "%s: bad act %d", who, q.act);
+    if ((q.bn_scale == nullptr) != (q.bn_shift == nullptr)) return fail(LAFF_E_ARG, "%s: bn_scale/bn_shift must come together", who);
+    if ((q.bias && !aligned16(q.bias)) || (q.bn_scale && (!aligned16(q.bn_scale) || !aligned16(q.bn_shift))))
+        return fail(LAFF_E_ALIGN, "%s: bias / bn_scale / bn_shift must be 16-byte aligned", who);
+    a = laff::GemmArgs{};
+    a.R = q.X; a.C = q.W; a.nR = q.N; a.nC = q.D; a.K = q.Dk; a.ldR = q.ldx; a.ldC = q.ldw;
+    a.nseg = 1; a.segR[0] = a.segC[0] = 0;
+    a.out = q.Y; a.ldo = q.ldy; a.scale = 1.0f;
+    a.bias = q.bias; a.bn_scale = q.bn_scale; a.bn_shift = q.bn_shift; a.act = q.act;
+    glds = aligned16(q.X) && aligned16(q.W) && (q.ldx % 4 == 0) && (q.ldw % 4 == 0) && (q.Dk % 4 == 0);
+    return LAFF_OK;
+}
+
 int laff_fc_act_bn(laff_ctx* ctx, const float* X, int N, int Dk, int ldx, const float* W, int ldw, const float* bias,
                    const float* bn_scale, const float* bn_shift, int D, int act, float* Y, int ldy) {
     CHECK_CTX(ctx);
-    if (!X || !W || !Y) return fail(LAFF_E_ARG, "laff_fc_act_bn: null X/W/Y");
-    if (N < 0 || Dk < 1 || D < 1 || ldx < Dk || ldw < Dk || ldy < D)
-        return fail(LAFF_E_SHAPE, "laff_fc_act_bn: bad shape N=%d Dk=%d D=%d ldx=%d ldw=%d ldy=%d", N, Dk, D, ldx, ldw, ldy);
-    if (act < LAFF_ACT_NONE || act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fc_act_bn: bad act %d", act);
-    if ((bn_scale == nullptr) != (bn_shift == nullptr)) return fail(LAFF_E_ARG, "laff_fc_act_bn: bn_scale/bn_shift must come together");
+    laff_fc_problem q{X, N, Dk, ldx, W, ldw, bias, bn_scale, bn_shift, D, act, Y, ldy};
+    laff::GemmArgs a;
+    bool glds;
+    if (int rc = fc_problem_args(q, a, glds, "laff_fc_act_bn")) return rc;
     if (N == 0) return LAFF_OK;
     DeviceGuard g(ctx->device);
-    laff::GemmArgs a{};
-    a.R = X; a.C = W; a.nR = N; a.nC = D; a.K = Dk; a.ldR = ldx; a.ldC = ldw;
-    a.nseg = 1; a.segR[0] = a.segC[0] = 0;
-    a.out = Y; a.ldo = ldy; a.scale = 1.0f;
-    a.bias = bias; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.act = act;
-    const bool glds = aligned16(X) && aligned16(W) && (ldx % 4 == 0) && (ldw % 4 == 0) && (Dk % 4 == 0);
     HIP_TRY(laff::launch_gemm_nt(a, laff::GEMM_F32, glds, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_fc_act_bn_grouped(laff_ctx* ctx, const laff_fc_problem* problems, int count) {
+    CHECK_CTX(ctx);
+    if (!problems || count < 0) return fail(LAFF_E_ARG, "laff_fc_act_bn_grouped: bad problem list");
+    DeviceGuard g(ctx->device);
+    // problems are grouped by staging kind (see staging_kind), at most MAX_GROUP per launch
+    for (int kind = 2; kind >= 0; --kind) {
+        laff::GroupedGemmArgs ga{};
+        for (int i = 0; i < count; ++i) {
+            laff::GemmArgs a;
+            bool aligned;
+            if (int rc = fc_problem_args(problems[i], a, aligned, "laff_fc_act_bn_grouped")) return rc;
+            if (problems[i].N == 0 || laff::staging_kind(a, 4, aligned, 128) != kind) continue;
+            ga.p[ga.count++] = a;
+            if (ga.count == laff::MAX_GROUP) {
+                HIP_TRY(laff::launch_gemm_nt_grouped_f32(ga, kind, ctx->stream));
+                ga.count = 0;
+            }
+        }
+        if (ga.count) HIP_TRY(laff::launch_gemm_nt_grouped_f32(ga, kind, ctx->stream));
+    }
     return LAFF_OK;
 }
 
@@ -264,32 +305,34 @@ int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const
     return LAFF_OK;
 }
 
+int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
+                    const int* gt_col, int col0, float* s_gt) {
+    CHECK_CTX(ctx);
+    if (!T || !V || !gt_col || !s_gt) return fail(LAFF_E_ARG, "laff_row_dot_gt: null argument");
+    if (precision < LAFF_PREC_FP16 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_UNSUPPORTED, "laff_row_dot_gt: 16-bit precisions only (got %d)", precision);
+    if (Nt < 0 || Nv < 0 || K < 8 || (K & 7)) return fail(LAFF_E_SHAPE, "laff_row_dot_gt: need K%%8==0 (K=%d)", K);
+    if (!aligned16(T) || !aligned16(V)) return fail(LAFF_E_ALIGN, "laff_row_dot_gt: operands must be 16-byte aligned");
+    if (Nt == 0) return LAFF_OK;
+    const int bf16 = (precision == LAFF_PREC_BF16 || precision == LAFF_PREC_BF16X3);
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_row_dot_gt(T, V, Nt, Nv, K, bf16, is_x3(precision) ? 1 : 0, scale, gt_col, col0, s_gt, ctx->stream));
+    return LAFF_OK;
+}
+
 int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, double out7[7]) {
     CHECK_CTX(ctx);
     if (!rank1 || !out7) return fail(LAFF_E_ARG, "laff_rank_metrics: null argument");
     if (Nq < 1) return fail(LAFF_E_SHAPE, "laff_rank_metrics: Nq=%d", Nq);
     DeviceGuard g(ctx->device);
-    std::vector<int> r(Nq);
-    HIP_TRY(hipMemcpyAsync(r.data(), rank1, sizeof(int) * (size_t)Nq, hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->d_metrics) {
+        HIP_TRY(hipMalloc((void**)&ctx->d_metrics, 8 * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
+    }
+    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, ctx->d_metrics, (int*)(ctx->d_metrics + 7), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_metrics, ctx->d_metrics, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    // evaluation.eval (/root/reference/evaluation.py:92-109) with one ground truth per row: AP = 1/rank
-    double c1 = 0, c5 = 0, c10 = 0, sum = 0, isum = 0;
-    for (int i = 0; i < Nq; ++i) {
-        const int v = r[i];
-        if (v < 1) return fail(LAFF_E_ARG, "laff_rank_metrics: rank1[%d]=%d is not 1-based", i, v);
-        c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
-        sum += v; isum += 1.0 / v;
-    }
-    std::vector<int> s(r);
-    const size_t mid = (size_t)Nq / 2;
-    std::nth_element(s.begin(), s.begin() + mid, s.end());
-    double med = s[mid];
-    if ((Nq & 1) == 0) {
-        const int lo = *std::max_element(s.begin(), s.begin() + mid);
-        med = 0.5 * (med + lo);
-    }
-    out7[0] = 100.0 * (c1 / Nq); out7[1] = 100.0 * (c5 / Nq); out7[2] = 100.0 * (c10 / Nq);   // numpy: 100.0 * mean
-    out7[3] = std::floor(med); out7[4] = sum / Nq; out7[5] = isum / Nq; out7[6] = isum / Nq;
+    if (*(const int*)(ctx->h_metrics + 7)) return fail(LAFF_E_ARG, "laff_rank_metrics: ranks must be 1-based (found a value < 1)");
+    for (int i = 0; i < 7; ++i) out7[i] = ctx->h_metrics[i];
     return LAFF_OK;
 }
 

@@ -31,46 +31,66 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0, 0, 0, 0};
 
 constexpr int TILE = 128;          // output tile edge
-constexpr int ROWB = 128;          // bytes of K per row per K-step
-constexpr int OPB = TILE * ROWB;   // 16 KiB per operand per stage
-constexpr int STAGEB = 2 * OPB;    // 32 KiB per stage
+// ROWB = bytes of K per row per K-step (template parameter: 128 or 64); one operand tile = TILE*ROWB bytes
 
 template <int MODE> struct ModeTraits;
 template <> struct ModeTraits<GEMM_F32> { static constexpr int ESZ = 4; };
 template <> struct ModeTraits<GEMM_F16> { static constexpr int ESZ = 2; };
 template <> struct ModeTraits<GEMM_BF16> { static constexpr int ESZ = 2; };
 
+// tanh / sigmoid on the hardware exp2 + rcp (v_exp_f32, v_rcp_f32: ~1 ulp each): |error| <= ~2e-7 absolute, checked
+// against tanhf in tests/test_gpu_kernels.py.  ocml's tanhf costs ~100 instructions per value, which at 64 outputs
+// per lane is as long as the tile's whole fp32 MFMA stream.
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 2.885390081777927f);     // e^(2x); inf / 0 saturate correctly
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
-        case 1: return tanhf(v);
+        case 1: return fast_tanh(v);
         case 2: return fmaxf(v, 0.0f);
-        case 3: return 1.0f / (1.0f + expf(-v));
+        case 3: return fast_sigmoid(v);
         default: return v;
     }
 }
 
 // ---- staging ----------------------------------------------------------------------------------------------
-// One operand tile = 128 rows x 8 chunks of 16 B.  LDS slot p (16-B units) = row*8 + cs holds source chunk
-// c = cs ^ ((row>>1)&7) of that row.
-template <bool GLDS>
+// One operand tile = 128 rows x ROWB/16 chunks of 16 B.  LDS slot p (16-B units) = row*CPR + cs holds source chunk
+// c = cs ^ swz(row) of that row; swz spreads each ds_read_b128 lane group over all 16 slots of the 256-B bank row:
+// ROWB=128: (row>>1)&7 (2 rows per bank row), ROWB=64: (row>>2)&3 (4 rows per bank row).
+template <bool GLDS, int ROWB>
 __device__ __forceinline__ void stage_operand(const char* __restrict__ base, int row0, int nrows, long ldb /*bytes*/,
                                               long kbyte0, long kbytes_valid /*bytes of K in this segment*/,
-                                              char* lds_op, int tid) {
+                                              char* lds_op, unsigned lds_op_addr, int tid) {
+    constexpr int CPR = ROWB / 16;               // 16-byte chunks per row
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int p = it * 256 + tid;            // 0..1023
-        const int row = p >> 3;
-        const int cs = p & 7;
-        const int c = cs ^ ((row >> 1) & 7);
+    for (int it = 0; it < TILE * CPR / 256; ++it) {
+        const int p = it * 256 + tid;
+        const int row = p / CPR;
+        const int cs = p % CPR;
+        const int c = ROWB == 128 ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
         int gr = row0 + row;
         gr = gr < nrows ? gr : nrows - 1;        // clamp: garbage rows are never stored
         const long kb = kbyte0 + (long)c * 16;
         if constexpr (GLDS) {
             const char* src = (kb + 16 <= kbytes_valid) ? base + (long)gr * ldb + kb : (const char*)g_zero16;
-            // wave-uniform LDS base + lane*16: slot index of lane 0 of this wave for this round
-            char* dst = lds_op + (size_t)(it * 256 + (tid & ~63)) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            // LDS-DMA: 16 B per lane land at (wave-uniform M0 base) + lane*16.  Issued from inline asm so that hipcc
+            // neither counts it nor forces `s_waitcnt vmcnt(0)` in front of every ds_read (it cannot prove the DMA
+            // targets the other ring slot); completion is tracked by hand with counted vmcnt in the main loop.
+            const unsigned dst = lds_op_addr + (unsigned)(it * 256 + (tid & ~63)) * 16u;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
+                : "memory");
         } else {
             // generic path: element-wise bounds (K tail / unaligned rows), through registers
             uint32_t v[4] = {0, 0, 0, 0};
@@ -89,31 +109,65 @@ __device__ __forceinline__ void stage_operand(const char* __restrict__ base, int
     }
 }
 
+template <int ROWB>
 __device__ __forceinline__ uint4 lds_frag(const char* lds_op, int row, int chunk) {
-    const int cs = chunk ^ ((row >> 1) & 7);
+    const int cs = ROWB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
     return *(const uint4*)(lds_op + row * ROWB + cs * 16);
 }
 
+// Fast staging (K*esz %% ROWB == 0, operand < 4 GiB): the per-lane part of every source address is a 32-bit byte
+// offset computed ONCE per tile; a K-step only advances a scalar base (saddr form), so the loop carries no VALU.
+template <int IT>
+__device__ __forceinline__ void glds_issue(const unsigned (&off)[IT], unsigned long long sbase, unsigned dst0) {
+    static_assert(IT == 2 || IT == 4, "");
+    unsigned keep;
+    const unsigned d0 = __builtin_amdgcn_readfirstlane(dst0);
+    if constexpr (IT == 4) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+            "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+            "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+            "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(sbase), "s"(d0), "s"(d0 + 4096u), "s"(d0 + 8192u),
+              "s"(d0 + 12288u)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+            "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(off[0]), "v"(off[1]), "s"(sbase), "s"(d0), "s"(d0 + 4096u)
+            : "memory");
+    }
+}
+
 // ---- kernel -----------------------------------------------------------------------------------------------
-template <int MODE, bool GLDS>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// blockIdx -> linear tile id such that each XCD (block b runs on XCD b % 8) works on a contiguous chunk of tiles
+// and neighbouring tiles share operand panels in that XCD's L2 (bijective for any nb).
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int MODE, int STG, int NS, int ROWB>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char* smem) {
     constexpr int ESZ = ModeTraits<MODE>::ESZ;
+    constexpr int OPB = TILE * ROWB, STAGEB = 2 * OPB;
+    constexpr bool GLDS = STG != 0;
+    constexpr int IT = TILE * (ROWB / 16) / 256;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, hh = lane >> 5;
 
-    // ---- block -> tile: XCD-contiguous chunks (bijective), then groups of 8 tile rows swept along c
+    // groups of 8 tile rows swept along c: 8 R panels + 8 C panels live in L2 at a time
     const int tiles_r = (a.nR + TILE - 1) / TILE, tiles_c = (a.nC + TILE - 1) / TILE;
-    const int nb = tiles_r * tiles_c;
-    int lin;
-    {
-        const int bid = blockIdx.x;
-        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int gsz_full = 8 * tiles_c;
     const int grp = lin / gsz_full;
     const int first_r = grp * 8;
@@ -136,30 +190,65 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+    // per-lane source offsets of this tile (fast path): slot p = it*256 + tid -> (row, swizzled chunk)
+    unsigned offR[IT], offC[IT];
+    if constexpr (STG == 2) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            constexpr int CPR = ROWB / 16;
+            const int p = it * 256 + tid;
+            const int row = p / CPR, cs = p % CPR;
+            const int c = ROWB == 128 ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+            offR[it] = (unsigned)min(r0 + row, a.nR - 1) * (unsigned)ldRb + (unsigned)c * 16u;
+            offC[it] = (unsigned)min(c0 + row, a.nC - 1) * (unsigned)ldCb + (unsigned)c * 16u;
+        }
+    }
     auto stage = [&](int kt, int buf) {
         const int seg = kt / kt_per_seg;
         const long kb0 = (long)(kt - seg * kt_per_seg) * ROWB;
         char* s = smem + buf * STAGEB;
-        stage_operand<GLDS>((const char*)a.R + a.segR[seg], r0, a.nR, ldRb, kb0, Kb, s, tid);
-        stage_operand<GLDS>((const char*)a.C + a.segC[seg], c0, a.nC, ldCb, kb0, Kb, s + OPB, tid);
+        const unsigned sa = lds0 + (unsigned)buf * STAGEB;
+        if constexpr (STG == 2) {
+            const unsigned wbase = (unsigned)(tid & ~63) * 16u;
+            glds_issue<IT>(offR, (unsigned long long)((const char*)a.R + a.segR[seg] + kb0), sa + wbase);
+            glds_issue<IT>(offC, (unsigned long long)((const char*)a.C + a.segC[seg] + kb0), sa + OPB + wbase);
+        } else {
+            stage_operand<GLDS, ROWB>((const char*)a.R + a.segR[seg], r0, a.nR, ldRb, kb0, Kb, s, sa, tid);
+            stage_operand<GLDS, ROWB>((const char*)a.C + a.segC[seg], c0, a.nC, ldCb, kb0, Kb, s + OPB, sa + OPB, tid);
+        }
     };
+    constexpr int LOADS = 2 * (TILE * (ROWB / 16) / 256);    // LDS-DMA instructions per thread per stage
 
-    stage(0, 0);
-    __syncthreads();
+    // ring of NS stages, prefetch distance NS-1, ONE barrier per K-step:
+    //   wait(stage kt landed) -> barrier -> issue stage kt+NS-1 into the slot read in step kt-1 -> compute(kt)
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nkt) stage(p, p);
 
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
-        const char* sR = smem + buf * STAGEB;
+        if constexpr (GLDS) {
+            // loads retire in order: stage kt is done when at most (stages issued after it) * LOADS remain
+            const int after = min(nkt - 1 - kt, NS - 2);
+            if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+            else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+        if (kt + NS - 1 < nkt) stage(kt + NS - 1, (kt + NS - 1) % NS);
+        const char* sR = smem + (kt % NS) * STAGEB;
         const char* sC = sR + OPB;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < ROWB / 32; ++ks) {
             const int chunk = 2 * ks + hh;
             uint4 fc[2], fr[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                fc[t] = lds_frag(sC, wc * 64 + t * 32 + l31, chunk);
-                fr[t] = lds_frag(sR, wr * 64 + t * 32 + l31, chunk);
+                fc[t] = lds_frag<ROWB>(sC, wc * 64 + t * 32 + l31, chunk);
+                fr[t] = lds_frag<ROWB>(sR, wr * 64 + t * 32 + l31, chunk);
             }
 #pragma unroll
             for (int tr = 0; tr < 2; ++tr)
@@ -180,14 +269,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
                     }
                 }
         }
-        __syncthreads();
+        if constexpr (!GLDS) __syncthreads();
     }
 
-    // ---- epilogue: lane holds out[rr][cc..cc+3] for reg quad q of tile (tr,tc)
+    // ---- epilogue ----------------------------------------------------------------------------------------------
+    // Accumulator layout: lane (l31, hh) holds out[row l31 of the 32-row block][4 consecutive columns] per register
+    // quad.  The per-column epilogue (scale, bias, activation, folded BN, ground-truth patch + rank count) runs in
+    // that layout; the tile then goes through a wave-private LDS slab (32 x 64 fp32, row pitch 68 words) so that
+    // every global store instruction writes 4 rows x 256 contiguous bytes instead of 64 scattered 16-byte pieces.
+    __syncthreads();                                   // every wave is done reading the operand ring
+    constexpr int PITCH = 68;
+    static_assert(4 * 32 * PITCH * 4 <= NS * 2 * TILE * ROWB, "epilogue slabs must fit in the operand ring");
+    float* slab = (float*)smem + wave * (32 * PITCH);
     const bool vec_ok = a.out && ((a.ldo & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0);
+    const bool has_epi = a.bias || a.bn_scale || a.act;
+    const int cw0 = c0 + wc * 64;                      // first output column of this wave
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr) {
-        const int rr = r0 + wr * 64 + tr * 32 + l31;
+        const int rbase = r0 + wr * 64 + tr * 32;
+        const int rr = rbase + l31;
         const bool row_ok = rr < a.nR;
         int cnt = 0;
         int gt = -1;
@@ -200,63 +300,162 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
         for (int tc = 0; tc < 2; ++tc) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cc = c0 + wc * 64 + tc * 32 + 8 * q + 4 * hh;
+                const int cl = tc * 32 + 8 * q + 4 * hh;          // column inside the wave's 64
+                const int cc = cw0 + cl;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[tr][tc][4 * q + e] * a.scale;
-                if (a.bias || a.bn_scale || a.act) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = cc + e;
-                        if (c < a.nC) {
-                            float t = v[e];
-                            if (a.bias) t += a.bias[c];
-                            t = act_apply(t, a.act);
-                            if (a.bn_scale) t = t * a.bn_scale[c] + a.bn_shift[c];
-                            v[e] = t;
+                if (has_epi) {
+                    float bb[4] = {0, 0, 0, 0}, ss[4] = {1, 1, 1, 1}, hs[4] = {0, 0, 0, 0};
+                    if (cc + 3 < a.nC) {          // per-column parameters as 16-byte loads (rows are 16-byte aligned)
+                        if (a.bias) *(float4*)bb = *(const float4*)(a.bias + cc);
+                        if (a.bn_scale) {
+                            *(float4*)ss = *(const float4*)(a.bn_scale + cc);
+                            *(float4*)hs = *(const float4*)(a.bn_shift + cc);
                         }
-                    }
-                }
-                if (a.count && row_ok) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = cc + e;
-                        cnt += (c < a.nC && c != gt && v[e] > sg) ? 1 : 0;
-                    }
-                }
-                if (a.out && row_ok) {
-                    float* o = a.out + (long)rr * a.ldo + cc;
-                    if (vec_ok && cc + 3 < a.nC) {
-                        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (cc + e < a.nC) o[e] = v[e];
+                            if (cc + e < a.nC) {
+                                if (a.bias) bb[e] = a.bias[cc + e];
+                                if (a.bn_scale) { ss[e] = a.bn_scale[cc + e]; hs[e] = a.bn_shift[cc + e]; }
+                            }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(act_apply(v[e] + bb[e], a.act), ss[e], hs[e]);
+                }
+                if (a.count && row_ok) {
+                    // the ground-truth entry is DEFINED by the pre-pass value s_gt (laff_row_dot_gt); writing it into S
+                    // keeps "rank counted here" == "rank recounted from S" exactly
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = cc + e;
+                        if (c == gt) v[e] = sg;
+                        cnt += (c < a.nC && c != gt && v[e] > sg) ? 1 : 0;
                     }
                 }
+                if (a.out) *(float4*)(slab + l31 * PITCH + cl) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
         if (a.count) {
             cnt += __shfl_xor(cnt, 32);
             if (hh == 0 && row_ok && cnt) atomicAdd(a.count + rr, cnt);
         }
+        if (a.out) {
+            __builtin_amdgcn_wave_barrier();
+            const int col4 = (lane & 15) * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = (lane >> 4) + 4 * j;
+                const float4 v = *(const float4*)(slab + row * PITCH + col4);
+                const int gr = rbase + row, gc = cw0 + col4;
+                if (gr < a.nR) {
+                    float* o = a.out + (long)gr * a.ldo + gc;
+                    if (vec_ok && gc + 3 < a.nC) {
+                        *(float4*)o = v;
+                    } else {
+                        const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (gc + e < a.nC) o[e] = t[e];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();            // slab is rewritten by the next 32-row block
+        }
     }
 }
 
-template <int MODE, bool GLDS>
+constexpr int waves_per_simd(int ns, int rowb) {    // workgroups per CU by LDS (160 KiB), capped at 4 by the VGPR budget
+    const int by_lds = (160 * 1024) / (ns * 2 * TILE * rowb);
+    return by_lds > 4 ? 4 : (by_lds < 1 ? 1 : by_lds);
+}
+
+template <int MODE, int STG, int NS, int ROWB>
+__global__ __launch_bounds__(256, waves_per_simd(NS, ROWB)) void gemm_nt_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_r = (a.nR + TILE - 1) / TILE, tiles_c = (a.nC + TILE - 1) / TILE;
+    gemm_tile<MODE, STG, NS, ROWB>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), smem);
+}
+
+// several independent problems (the FC projections of all fused features) in ONE launch: fills the chip where a
+// single 10k-row projection has only 316 tiles for 512 workgroup slots, and removes 7 launch boundaries.
+template <int MODE, int STG, int NS, int ROWB>
+__global__ __launch_bounds__(256, waves_per_simd(NS, ROWB)) void gemm_nt_grouped_kernel(GroupedGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lin = xcd_remap(blockIdx.x, g.tile_start[g.count]);
+    int p = 0;
+    while (p + 1 < g.count && lin >= g.tile_start[p + 1]) ++p;     // wave-uniform scalar search
+    gemm_tile<MODE, STG, NS, ROWB>(g.p[p], lin - g.tile_start[p], smem);
+}
+
+template <typename K>
+static hipError_t set_smem(K kernel, int smem) {
+    if (smem > 64 * 1024) return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    return hipSuccess;
+}
+
+template <int MODE, int STG, int NS, int ROWB>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_r = (a.nR + TILE - 1) / TILE, tiles_c = (a.nC + TILE - 1) / TILE;
     const long nb = (long)tiles_r * tiles_c;
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_nt_kernel<MODE, GLDS>), dim3((unsigned)nb), dim3(256), 2 * STAGEB, st, a);
+    constexpr int smem = NS * 2 * TILE * ROWB;
+    hipError_t e = set_smem(gemm_nt_kernel<MODE, STG, NS, ROWB>, smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gemm_nt_kernel<MODE, STG, NS, ROWB>), dim3((unsigned)nb), dim3(256), smem, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool glds, hipStream_t st) {
+// staging kind of one problem: 0 = through registers (unaligned rows / ragged K), 1 = LDS-DMA with per-step address
+// arithmetic (ragged K tail), 2 = LDS-DMA fast path (K bytes a multiple of the K-step, operands below 4 GiB)
+int staging_kind(const GemmArgs& a, int esz, bool aligned, int rowb) {
+    if (!aligned) return 0;
+    const long long Kb = (long long)a.K * esz;
+    const long long spanR = (long long)a.nR * a.ldR * esz, spanC = (long long)a.nC * a.ldC * esz;
+    if (Kb % rowb == 0 && spanR < (1ll << 32) && spanC < (1ll << 32)) return 2;
+    return 1;
+}
+
+int g_gemm_variant = 0;   // reserved tuning knob (LAFF_GEMM_VARIANT)
+
+template <int MODE>
+static hipError_t launch_m(const GemmArgs& a, bool aligned, hipStream_t st) {
+    const int esz = ModeTraits<MODE>::ESZ;
+    const int rowb = 128;
+    const int stg = staging_kind(a, esz, aligned, rowb);
+    if (stg == 0) return launch_t<MODE, 0, 2, 128>(a, st);
+    if (stg == 1) return launch_t<MODE, 1, 2, 128>(a, st);
+    return launch_t<MODE, 2, 2, 128>(a, st);
+}
+
+template <int STG>
+static hipError_t launch_grouped_t(GroupedGemmArgs& g, hipStream_t st) {
+    long nb = 0;
+    for (int i = 0; i < g.count; ++i) {
+        g.tile_start[i] = (int)nb;
+        nb += (long)((g.p[i].nR + TILE - 1) / TILE) * ((g.p[i].nC + TILE - 1) / TILE);
+    }
+    if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
+    g.tile_start[g.count] = (int)nb;
+    constexpr int smem = 2 * 2 * TILE * 128;
+    hipLaunchKernelGGL((gemm_nt_grouped_kernel<GEMM_F32, STG, 2, 128>), dim3((unsigned)nb), dim3(256), smem, st, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int stg, hipStream_t st) {
+    switch (stg) {
+        case 0: return launch_grouped_t<0>(g, st);
+        case 1: return launch_grouped_t<1>(g, st);
+        default: return launch_grouped_t<2>(g, st);
+    }
+}
+
+hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool aligned, hipStream_t st) {
     switch (mode) {
-        case GEMM_F32: return glds ? launch_t<GEMM_F32, true>(a, st) : launch_t<GEMM_F32, false>(a, st);
-        case GEMM_F16: return glds ? launch_t<GEMM_F16, true>(a, st) : launch_t<GEMM_F16, false>(a, st);
-        case GEMM_BF16: return glds ? launch_t<GEMM_BF16, true>(a, st) : launch_t<GEMM_BF16, false>(a, st);
+        case GEMM_F32: return launch_m<GEMM_F32>(a, aligned, st);
+        case GEMM_F16: return launch_m<GEMM_F16>(a, aligned, st);
+        case GEMM_BF16: return launch_m<GEMM_BF16>(a, aligned, st);
     }
     return hipErrorInvalidValue;
 }

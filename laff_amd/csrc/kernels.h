@@ -31,7 +31,17 @@ struct GemmArgs {
     int* count;
 };
 
-hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool glds, hipStream_t st);
+constexpr int MAX_GROUP = 8;
+struct GroupedGemmArgs {
+    int count;
+    int tile_start[MAX_GROUP + 1];
+    GemmArgs p[MAX_GROUP];
+};
+
+hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool aligned, hipStream_t st);
+hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int staging, hipStream_t st);
+int staging_kind(const GemmArgs& a, int esz, bool aligned, int rowb);
+extern int g_gemm_variant;
 
 constexpr int MAX_L = 8;
 struct FuseArgs {
@@ -66,6 +76,9 @@ hipError_t launch_frame_fuse(const FrameArgs& a, hipStream_t st);
 hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,
                             int precision, void* out, hipStream_t st);
 
+hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K, int bf16, int x3, float scale,
+                             const int* gt_col, int col0, float* s_gt, hipStream_t st);
+hipError_t launch_rank_metrics(const int* rank1, int n, double* out7, int* err, hipStream_t st);
 hipError_t launch_gather_gt(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt,
                             hipStream_t st);
 hipError_t launch_rank_count(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, const float* s_gt,

@@ -99,6 +99,131 @@ __global__ __launch_bounds__(256) void v2t_count_kernel(const float* __restrict_
     }
 }
 
+// s_gt[t] = scale * <T[t,:], V[gt[t]-col0,:]> on the packed 16-bit GEMM operands (fp32 accumulate, sequential per lane
+// + wave tree), -inf when the column is not in this shard.  One wavefront per text row.  x3: hi*hi + hi*lo + lo*hi.
+template <bool BF16>
+__global__ __launch_bounds__(256) void row_dot_gt_kernel(const uint16_t* __restrict__ T, const uint16_t* __restrict__ V, int Nt,
+                                                         int Nv, int K, int x3, float scale, const int* __restrict__ gt_col,
+                                                         int col0, float* __restrict__ s_gt) {
+    const int lane = threadIdx.x & 63;
+    const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= Nt) return;
+    const int c = gt_col[t] - col0;
+    if (c < 0 || c >= Nv) {
+        if (lane == 0) s_gt[t] = -INFINITY;
+        return;
+    }
+    auto cvt = [](uint16_t h) -> float {
+        if constexpr (BF16) return __uint_as_float((unsigned)h << 16);
+        else { _Float16 f; __builtin_memcpy(&f, &h, 2); return (float)f; }
+    };
+    const uint16_t* tr = T + t * K;
+    const uint16_t* vr = V + (long)c * K;
+    const long pT = (long)Nt * K, pV = (long)Nv * K;
+    float acc = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        uint4 a = *(const uint4*)(tr + k), b = *(const uint4*)(vr + k);
+        const uint16_t* pa = (const uint16_t*)&a;
+        const uint16_t* pb = (const uint16_t*)&b;
+        if (x3) {
+            uint4 al = *(const uint4*)(tr + pT + k), bl = *(const uint4*)(vr + pV + k);
+            const uint16_t* pal = (const uint16_t*)&al;
+            const uint16_t* pbl = (const uint16_t*)&bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += cvt(pal[e]) * cvt(pb[e]) + cvt(pa[e]) * cvt(pbl[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(cvt(pa[e]), cvt(pb[e]), acc);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) s_gt[t] = acc * scale;
+}
+
+hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K, int bf16, int x3, float scale,
+                             const int* gt_col, int col0, float* s_gt, hipStream_t st) {
+    const unsigned grid = (unsigned)((Nt + 3) / 4);
+    if (bf16)
+        hipLaunchKernelGGL((row_dot_gt_kernel<true>), dim3(grid), dim3(256), 0, st, (const uint16_t*)T, (const uint16_t*)V, Nt, Nv, K, x3, scale, gt_col, col0, s_gt);
+    else
+        hipLaunchKernelGGL((row_dot_gt_kernel<false>), dim3(grid), dim3(256), 0, st, (const uint16_t*)T, (const uint16_t*)V, Nt, Nv, K, x3, scale, gt_col, col0, s_gt);
+    return hipGetLastError();
+}
+
+// evaluation.eval (/root/reference/evaluation.py:92-109) for single-GT rows, on the device: one 1024-thread block.
+// out7 = r1, r5, r10, medr, meanr, mir, mAP (= mir).  err[0] != 0 if a rank < 1 was seen.
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    return t;
+}
+__device__ __forceinline__ int block_max(int v, double* sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = (double)v;
+    __syncthreads();
+    double t = sh[0];
+    for (int i = 1; i < 16; ++i) t = fmax(t, sh[i]);
+    return (int)t;
+}
+
+__global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, double* __restrict__ out7,
+                                                            int* __restrict__ err) {
+    __shared__ double sh[16];
+    double c1 = 0, c5 = 0, c10 = 0, sum = 0, isum = 0;
+    int mx = 0, mn = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int v = r[i];
+        c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
+        sum += v; isum += 1.0 / (double)v;
+        mx = max(mx, v); mn = min(mn, v);
+    }
+    c1 = block_sum(c1, sh); c5 = block_sum(c5, sh); c10 = block_sum(c10, sh);
+    sum = block_sum(sum, sh); isum = block_sum(isum, sh);
+    mx = block_max(mx, sh);
+    mn = -block_max(-mn, sh);
+    // k-th smallest (0-based k = n/2) by bisection on the value: smallest v with #{r <= v} >= k+1
+    const int k = n / 2;
+    int lo = mn, hi = mx;
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        double c = 0;
+        for (int i = threadIdx.x; i < n; i += 1024) c += r[i] <= mid;
+        c = block_sum(c, sh);
+        if (c >= k + 1) hi = mid; else lo = mid + 1;
+    }
+    double med = lo;
+    if ((n & 1) == 0) {
+        // sorted[k-1]: equals sorted[k] unless exactly k elements are smaller, then it is the largest of those
+        double cl = 0;
+        int below = 0;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const int v = r[i];
+            if (v < lo) { cl += 1; below = max(below, v); }
+        }
+        cl = block_sum(cl, sh);
+        below = block_max(below, sh);
+        const double prev = (cl >= k) ? (double)below : (double)lo;
+        med = 0.5 * (med + prev);
+    }
+    if (threadIdx.x == 0) {
+        out7[0] = 100.0 * (c1 / n); out7[1] = 100.0 * (c5 / n); out7[2] = 100.0 * (c10 / n);
+        out7[3] = floor(med); out7[4] = sum / n; out7[5] = isum / n; out7[6] = isum / n;
+        err[0] = mn < 1 ? 1 : 0;
+    }
+}
+
+hipError_t launch_rank_metrics(const int* rank1, int n, double* out7, int* err, hipStream_t st) {
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(1024), 0, st, rank1, n, out7, err);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_gt(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt,
                             hipStream_t st) {
     hipLaunchKernelGGL(gather_gt_kernel, dim3((Nt + 255) / 256), dim3(256), 0, st, S, Nt, Nv, (long)lds, gt_col, col0, s_gt);

@@ -32,6 +32,11 @@ class HipBackend:
     def __init__(self, model, precision='fp16'):
         self.model, self.precision = model, precision
 
+    def embed_both(self, vis_feats, txt_feats):
+        """Single-rank shortcut: both towers' FC projections in one grouped launch."""
+        from .retrieval import embed
+        return embed(self.model, vis_feats, txt_feats)
+
     def embed_text(self, txt_feats):
         cap = dict(txt_feats)
         cap.setdefault('caption', None)
@@ -54,18 +59,21 @@ class HipBackend:
     def sim(self, T, V, heads):
         return ops.sim_gemm(T, V, heads=heads)
 
-    def gather_gt(self, S, gt, col0):
-        return ops.gather_gt(S, gt, col0)
+    def row_dot_gt(self, T, V, gt, heads, col0):
+        return ops.row_dot_gt(T, V, gt, heads, col0)
 
-    def rank_count(self, S, gt, s_gt, col0):
-        return ops.rank_count(S, gt, s_gt, col0)
+    def sim_ranked(self, T, V, heads, gt, s_gt, col0, want_scores=True):
+        """Score block + ground-truth rank counts in one GEMM launch (fused epilogue)."""
+        count = torch.zeros((T.N,), dtype=torch.int32, device=T.buf.device)
+        S = ops.sim_gemm(T, V, heads=heads, want_scores=want_scores, gt_col=gt, s_gt=s_gt, count=count, col0=col0)
+        return S, count
 
     def metrics(self, ranks):
         return ops.rank_metrics(ranks)
 
 
 def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
-                     timer=None):
+                     timer=None, want_scores=True):
     """One pass of the hot path on this rank's shards.  gt: (Nt,) int32 GLOBAL video column of every text (replicated).
 
     Returns dict(S_local (Nt, v1-v0), col0, ranks (Nt,), metrics)."""
@@ -74,8 +82,13 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
     v0, v1 = shard_bounds(Nv, world, rank)
     mark = timer.mark if timer is not None else (lambda name: None)
     with torch.no_grad():
-        txt_emb = compute.embed_text(txt_feats_local)
-        mark('txt_tower')
+        vis_emb = None
+        if world == 1 and hasattr(compute, 'embed_both'):
+            vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local)
+            mark('towers')
+        else:
+            txt_emb = compute.embed_text(txt_feats_local)
+            mark('txt_tower')
         T_local = compute.pack(txt_emb)
         mark('pack')
         work = None
@@ -94,8 +107,9 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
             else:
                 raise NotImplementedError("sharded evaluation gathers a single-plane 16-bit operand; precision '%s' "
                                           "is single-GPU only for now" % T_local.precision)
-        vis_emb = compute.embed_video(vis_feats_local)
-        mark('vis_tower')
+        if vis_emb is None:
+            vis_emb = compute.embed_video(vis_feats_local)
+            mark('vis_tower')
         V_local = compute.pack(vis_emb)
         mark('pack')
         if world > 1:
@@ -109,12 +123,13 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
             mark('all_gather_wait')
         else:
             T_all = T_local
-        S_local = compute.sim(T_all, V_local, heads)
-        mark('sim_gemm')
-        s_gt = compute.gather_gt(S_local, gt, v0)
+        # ground-truth score from the shard that owns the column, then one GEMM that writes S and counts ranks
+        s_gt = compute.row_dot_gt(T_all, V_local, gt, heads, v0)
         if world > 1:
             dist.all_reduce(s_gt, op=dist.ReduceOp.MAX, group=group)
-        count = compute.rank_count(S_local, gt, s_gt, v0)
+        mark('s_gt')
+        S_local, count = compute.sim_ranked(T_all, V_local, heads, gt, s_gt, v0, want_scores)
+        mark('sim_gemm')
         if world > 1:
             dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
         ranks = count + 1

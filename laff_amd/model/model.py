@@ -118,14 +118,21 @@ class TransformNet(nn.Module):
             shift = (shift + extra_shift).contiguous()
         return scale, shift
 
-    def plane(self, x, heads=1, extra_shift=None):
-        """(src, tile, scale, shift) for laff_fuse; runs the FC GEMM when there is one."""
+    def plane(self, x, heads=1, extra_shift=None, pending=None):
+        """(src, tile, scale, shift) for laff_fuse.  With an FC the projection either runs now or, when `pending`
+        (a list) is given, is appended to it so that the caller launches all features' GEMMs as one grouped kernel."""
         _eval_only(self)
         x = to_device_and_float16(x)
         scale, shift = self.bn_affine(extra_shift)
         if self.fc1 is not None:
-            y = ops.fc_act_bn(x, self.fc1.weight.detach(), self.fc1.bias.detach() if self.fc1.bias is not None else None,
-                              scale, shift, self.activation_name)
+            prob = dict(x=x, weight=self.fc1.weight.detach(),
+                        bias=self.fc1.bias.detach() if self.fc1.bias is not None else None,
+                        bn_scale=scale, bn_shift=shift, activation=self.activation_name)
+            if pending is None:
+                y = ops.fc_act_bn_grouped([prob])[0]
+            else:
+                y = prob['out'] = torch.empty((x.shape[0], self.out_features), device=x.device, dtype=torch.float32)
+                pending.append(prob)
             return (y, False, None, None)
         if self.activation_name is not None:
             raise NotImplementedError('activation without fc is never built by the reference towers')
@@ -178,7 +185,7 @@ class VisMutiTransformNet(nn.Module):
                 self.add_module(each, TransformNet((space_dict[each], opt.vis_fc_layers[1]), None, dropout=None,
                                                    batch_norm=True, activation=False, fc=False))
 
-    def planes(self, vis_input, expert=None):
+    def planes(self, vis_input, expert=None, pending=None):
         if self.opt.vis_feat_add_concat and 'vis_feat_add_concat' not in vis_input:
             vis_input['vis_feat_add_concat'] = torch.cat([to_device_and_float16(v) for v in vis_input.values()], dim=1)
         heads = self.opt.multi_head_attention['heads']
@@ -187,12 +194,14 @@ class VisMutiTransformNet(nn.Module):
         for i, name in enumerate(self.vis_net_space_dict.keys()):
             vis_input[name] = to_device_and_float16(vis_input[name])     # in-place like the reference (:1817)
             h = heads if name in self.opt.vis_no_transform else 1
-            out.append(module_dict[name].plane(vis_input[name], h, None if expert is None else expert[i]))
+            out.append(module_dict[name].plane(vis_input[name], h, None if expert is None else expert[i], pending))
         return out
 
     def forward(self, vis_input, txt_emb=None, vis_frame_feat_dict_input=None):
         heads = self.opt.multi_head_attention['heads']
-        planes = self.planes(vis_input)
+        pending = []
+        planes = self.planes(vis_input, pending=pending)
+        ops.fc_act_bn_grouped(pending)
         return {name: _materialise(p, heads, self.common_space_dim)
                 for name, p in zip(self.vis_net_space_dict.keys(), planes)}
 
@@ -214,10 +223,18 @@ class VisMutiTransformNetAddAttnetion(nn.Module):
         if opt.vis_expert_embedding['l2norm']:
             raise NotImplementedError('vis_expert_embedding l2norm is off in every shipped config and not provided')
 
-    def forward(self, vis_input, txt_emb=None, vis_frame_feat_dict_input=None):
+    def prepare(self, vis_input, vis_frame_feat_dict_input=None, pending=None):
+        """Queue this tower's FC projections on `pending`; returns the closure that fuses once they have run."""
         _eval_only(self)
-        planes = self.VisMutiTransformNet.planes(vis_input, _expert_rows(self.expert_embedding, len(self.vis_net_space_dict)))
-        return _fuse(self.attention_layer, planes, self.opt.multi_head_attention['heads'])
+        planes = self.VisMutiTransformNet.planes(vis_input, _expert_rows(self.expert_embedding, len(self.vis_net_space_dict)),
+                                                 pending)
+        return lambda: _fuse(self.attention_layer, planes, self.opt.multi_head_attention['heads'])
+
+    def forward(self, vis_input, txt_emb=None, vis_frame_feat_dict_input=None):
+        pending = []
+        finish = self.prepare(vis_input, pending=pending)
+        ops.fc_act_bn_grouped(pending)
+        return finish()
 
     def get_attention_weight(self, vis_input, txt_emb=None):
         self.forward(vis_input, txt_emb)
@@ -303,7 +320,7 @@ class MultiScaleTxtEncoderAttention(nn.Module):
         if opt.txt_expert_embedding['l2norm']:
             raise NotImplementedError('txt_expert_embedding l2norm is off in every shipped config and not provided')
 
-    def forward(self, caption_feat_dict, visual_emb=None, task3=False):
+    def prepare(self, caption_feat_dict, pending=None, task3=False):
         _eval_only(self)
         heads = self.opt.multi_head_attention['heads']
         expert = _expert_rows(self.expert_embedding, len(self.encoder_name_list))
@@ -312,8 +329,14 @@ class MultiScaleTxtEncoderAttention(nn.Module):
             feats = getattr(self.encoder, name)(caption_feat_dict, task3=task3)['text_features']
             h = heads if name in self.opt.txt_no_transform else 1
             planes.append(getattr(self.transform_layer, name + '_transform').plane(
-                feats, h, None if expert is None else expert[i]))
-        return _fuse(self.attention_layer, planes, heads)
+                feats, h, None if expert is None else expert[i], pending))
+        return lambda: _fuse(self.attention_layer, planes, heads)
+
+    def forward(self, caption_feat_dict, visual_emb=None, task3=False):
+        pending = []
+        finish = self.prepare(caption_feat_dict, pending, task3)
+        ops.fc_act_bn_grouped(pending)
+        return finish()
 
     def get_attention_weight(self, caption_feat_dict, visual_emb=None):
         self.forward(caption_feat_dict, visual_emb)
@@ -372,6 +395,12 @@ class VisMutiTransformNetPlusFrameFeat(nn.Module):
         return ops.frame_fuse(frames, lens, w.reshape(-1), b, gw, ops.attention_flags(att.with_ave, att.mul))
 
     def forward(self, vis_input, vis_frame_feat_dict_input, txt_emb=None):
+        pending = []
+        finish = self.prepare(vis_input, vis_frame_feat_dict_input, pending)
+        ops.fc_act_bn_grouped(pending)
+        return finish()
+
+    def prepare(self, vis_input, vis_frame_feat_dict_input=None, pending=None):
         _eval_only(self)
         if self.opt.frame_feat_with_video_feat is False:
             vis_input = {}
@@ -387,8 +416,8 @@ class VisMutiTransformNetPlusFrameFeat(nn.Module):
         for name in vis_input.keys():
             vis_input[name] = to_device_and_float16(vis_input[name])
             h = heads if name in self.opt.vis_no_transform else 1
-            planes.append(module_dict[name].plane(vis_input[name], h))
-        return _fuse(self.vis_attention_layer, planes, heads)
+            planes.append(module_dict[name].plane(vis_input[name], h, None, pending))
+        return lambda: _fuse(self.vis_attention_layer, planes, heads)
 
     def get_attention_weight(self, vis_input, vis_frame_feat_dict_input):
         self.forward(vis_input, vis_frame_feat_dict_input)

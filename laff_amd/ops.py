@@ -10,9 +10,9 @@ import torch
 
 from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
-                   Plane, check)
+                   FcProblem, Plane, check)
 
-__all__ = ['fc_act_bn', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['fc_act_bn', 'fc_act_bn_grouped', 'row_dot_gt', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -89,6 +89,41 @@ def fc_act_bn(x, weight, bias=None, bn_scale=None, bn_shift=None, activation=Non
     _call('fc_act_bn', lib.laff_fc_act_bn, h, _ptr(x), N, Dk, ldx, _ptr(w), ldw, _ptr(bias), _ptr(bn_scale), _ptr(bn_shift), D,
                              ACT[activation], _ptr(y), ldy)
     return out
+
+
+def fc_act_bn_grouped(problems):
+    """Several independent projections in one launch.  problems: list of dicts with keys x, weight and optional
+    bias, bn_scale, bn_shift, activation, out.  Returns the list of outputs."""
+    if not problems:
+        return []
+    arr = (FcProblem * len(problems))()
+    outs, keep = [], []
+    for i, q in enumerate(problems):
+        x, ldx = _rows(q['x'], 'x')
+        w, ldw = _rows(q['weight'], 'weight')
+        N, Dk = x.shape
+        D = w.shape[0]
+        if w.shape[1] != Dk:
+            raise ValueError('problem %d: weight is %s but x has %d columns' % (i, tuple(w.shape), Dk))
+        vecs = []
+        for nm in ('bias', 'bn_scale', 'bn_shift'):
+            t = q.get(nm)
+            if t is not None:
+                _dev(t, nm)
+                if t.numel() != D or not t.is_contiguous():
+                    raise ValueError('%s must be a contiguous vector of %d' % (nm, D))
+            vecs.append(t)
+        out = q.get('out')
+        if out is None:
+            out = torch.empty((N, D), device=x.device, dtype=torch.float32)
+        y, ldy = _rows(out, 'out')
+        arr[i] = FcProblem(x.data_ptr(), N, Dk, ldx, w.data_ptr(), ldw, *[t.data_ptr() if t is not None else None for t in vecs],
+                           D, ACT[q.get('activation')], y.data_ptr(), ldy)
+        outs.append(out)
+        keep.append((x, w, vecs))
+    lib, h = _context(problems[0]['x'].device)
+    _call('fc_act_bn', lib.laff_fc_act_bn_grouped, h, arr, len(problems))
+    return outs
 
 
 def fuse(planes, H, d, w, b, gw, flags, return_weights=False):
@@ -190,6 +225,17 @@ def sim_gemm(T, V, heads=1, out=None, want_scores=True, gt_col=None, s_gt=None, 
     _call('sim_gemm', lib.laff_sim_gemm, h, _ptr(T.buf), _ptr(V.buf), T.N, V.N, T.K, scale, PREC[T.precision], _ptr(S), lds,
                             _ptr(gt_col), col0, _ptr(s_gt), _ptr(count))
     return S
+
+
+def row_dot_gt(T, V, gt_col, heads=1, col0=0):
+    """s_gt[t] = <T[t], V[gt[t]-col0]> / (heads * prescale^2) on the packed operands; -inf outside this shard."""
+    _dev(gt_col, 'gt_col', torch.int32)
+    out = torch.empty((T.N,), device=T.buf.device, dtype=torch.float32)
+    scale = 1.0 / (heads * T.prescale * V.prescale)
+    lib, h = _context(T.buf.device)
+    _call('row_dot_gt', lib.laff_row_dot_gt, h, _ptr(T.buf), _ptr(V.buf), T.N, V.N, T.K, scale, PREC[T.precision], _ptr(gt_col),
+          col0, _ptr(out))
+    return out
 
 
 def gather_gt(S, gt_col, col0=0):

@@ -19,24 +19,31 @@ def embed(model, vis_feats, txt_feats):
     frame_dict = {}
     if 'mask_tensor' in vis:                      # FrameLAFF workload: every video feature is a frame tensor
         frame_dict, vis = vis, {}
-    vis_emb = model.vis_net(vis, vis_frame_feat_dict_input=frame_dict)
     cap = dict(txt_feats)
     cap.setdefault('caption', None)
-    txt_emb = model.txt_net(cap)
-    return vis_emb, txt_emb
+    pending = []                                  # all FC projections of both towers -> ONE grouped launch
+    fin_v = model.vis_net.prepare(vis, frame_dict, pending)
+    fin_t = model.txt_net.prepare(cap, pending)
+    ops.fc_act_bn_grouped(pending)
+    return fin_v(), fin_t()
 
 
-def evaluate(model, vis_feats, txt_feats, gt, precision='fp16', write_scores=True, fused_rank=False, want_metrics=True):
-    """One pass of the hot path.  gt: int32 (Nt,) device tensor of ground-truth video columns."""
+def evaluate(model, vis_feats, txt_feats, gt, precision='fp16', write_scores=True, want_metrics=True):
+    """One pass of the hot path on one GPU.  gt: int32 (Nt,) device tensor of ground-truth video columns.
+    write_scores=False skips materialising S (ranks only)."""
     with torch.no_grad():
         vis_emb, txt_emb = embed(model, vis_feats, txt_feats)
         heads = vis_emb.shape[1] if vis_emb.dim() == 3 else 1
         T = ops.pack_rows(txt_emb, True, 1e-13, precision)
         V = ops.pack_rows(vis_emb, True, 1e-13, precision)
-        if fused_rank and not write_scores:
-            raise NotImplementedError('rank-only mode needs the ground-truth pre-pass (round 2)')
-        S = ops.sim_gemm(T, V, heads=heads)
-        s_gt = ops.gather_gt(S, gt)
-        ranks = ops.rank_count(S, gt, s_gt) + 1
+        if precision == 'fp32':
+            S = ops.sim_gemm(T, V, heads=heads)
+            s_gt = ops.gather_gt(S, gt)
+            count = ops.rank_count(S, gt, s_gt)
+        else:
+            s_gt = ops.row_dot_gt(T, V, gt, heads)
+            count = torch.zeros((T.N,), dtype=torch.int32, device=gt.device)
+            S = ops.sim_gemm(T, V, heads=heads, want_scores=write_scores, gt_col=gt, s_gt=s_gt, count=count)
+        ranks = count + 1
         metrics = ops.rank_metrics(ranks) if want_metrics else None
     return RetrievalResult(S, ranks, metrics, vis_emb, txt_emb)

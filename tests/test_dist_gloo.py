@@ -44,16 +44,19 @@ class OracleBackend:
     def sim(self, T, V, heads):
         return self._mat(T) @ self._mat(V).T
 
-    def gather_gt(self, S, gt, col0):
+    def row_dot_gt(self, T, V, gt, heads, col0):
+        S = self.sim(T, V, heads)
         c = gt.long() - col0
         ok = (c >= 0) & (c < S.shape[1])
         out = torch.full((S.shape[0],), float('-inf'))
         out[ok] = S[torch.arange(S.shape[0])[ok], c[ok]]
         return out
 
-    def rank_count(self, S, gt, s_gt, col0):
+    def sim_ranked(self, T, V, heads, gt, s_gt, col0, want_scores=True):
+        S = self.sim(T, V, heads)
         cols = torch.arange(S.shape[1])[None, :] + col0
-        return ((S > s_gt[:, None]) & (cols != gt.long()[:, None])).sum(dim=1).to(torch.int32)
+        count = ((S > s_gt[:, None]) & (cols != gt.long()[:, None])).sum(dim=1).to(torch.int32)
+        return S, count
 
     def metrics(self, ranks):
         r = ranks.numpy().astype(np.float64)

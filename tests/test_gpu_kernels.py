@@ -258,3 +258,66 @@ def test_sharded_rank_count_sums_to_global():
     for p, a in zip(parts, bounds[:-1]):
         total += ops.rank_count(p, gt, s_gt, col0=a)
     assert torch.equal(total, full)
+
+
+def test_fused_pipeline_is_self_consistent():
+    """row_dot_gt pre-pass + fused count: the rank recounted from the written S equals the fused rank EXACTLY,
+    and S[t, gt] carries the pre-pass value."""
+    from laff_amd import ops
+    g = rnd(79)
+    Nt, Nv, K = 700, 333, 512
+    t = g.normal(0, 1, (Nt, K)).astype(np.float32)
+    v = g.normal(0, 1, (Nv, K)).astype(np.float32)
+    gt = dev((np.arange(Nt) * 5 % Nv).astype(np.int32), torch.int32)
+    for prec in ('fp16', 'bf16', 'fp16x3', 'bf16x3'):
+        T = ops.pack_rows(dev(t), True, 1e-13, prec)
+        V = ops.pack_rows(dev(v), True, 1e-13, prec)
+        s_gt = ops.row_dot_gt(T, V, gt)
+        plain = ops.sim_gemm(T, V)
+        assert maxdiff(s_gt, ops.gather_gt(plain, gt)) <= 2e-6, prec       # same products, different fp32 order
+        cnt = torch.zeros(Nt, dtype=torch.int32, device=DEV)
+        S = ops.sim_gemm(T, V, gt_col=gt, s_gt=s_gt, count=cnt)
+        assert torch.equal(ops.gather_gt(S, gt), s_gt)
+        assert torch.equal(ops.rank_count(S, gt, s_gt), cnt)
+        mask = torch.ones_like(S, dtype=torch.bool)
+        mask[torch.arange(Nt, device=DEV), gt.long()] = False
+        assert torch.equal(S[mask], plain[mask])
+    # shard semantics: columns outside the shard give -inf
+    T = ops.pack_rows(dev(t), True, 1e-13, 'fp16')
+    V = ops.pack_rows(dev(v[100:200]), True, 1e-13, 'fp16')
+    s = ops.row_dot_gt(T, V, gt, col0=100).cpu().numpy()
+    inside = (gt.cpu().numpy() >= 100) & (gt.cpu().numpy() < 200)
+    assert np.all(np.isneginf(s[~inside])) and np.all(np.isfinite(s[inside]))
+
+
+def test_fc_grouped_equals_single():
+    from laff_amd import ops
+    g = rnd(80)
+    probs, singles = [], []
+    for (N, Dk, D, act) in [(300, 512, 512, 'tanh'), (77, 96, 260, None), (1, 4, 4, 'relu'), (513, 2048, 384, 'tanh'),
+                            (40, 77, 130, 'sigmoid')]:
+        x = dev(g.normal(0, 1, (N, Dk)).astype(np.float32))
+        W = dev((g.normal(0, 1, (D, Dk)) / np.sqrt(Dk)).astype(np.float32))
+        b = dev(g.normal(0, 0.1, D).astype(np.float32))
+        sc = dev(g.uniform(0.5, 1.5, D).astype(np.float32))
+        sh = dev(g.normal(0, 0.1, D).astype(np.float32))
+        probs.append(dict(x=x, weight=W, bias=b, bn_scale=sc, bn_shift=sh, activation=act))
+        singles.append(ops.fc_act_bn(x, W, b, sc, sh, act))
+    outs = ops.fc_act_bn_grouped(probs)
+    for a, b in zip(outs, singles):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 10, 1001, 40000])
+def test_rank_metrics_device_vs_numpy(n):
+    from laff_amd import ops
+    g = rnd(n)
+    r = g.integers(1, 3000, n).astype(np.int32)
+    r[: n // 3] = 1
+    got = ops.rank_metrics(dev(r, torch.int32))
+    ranks = r.astype(np.float64)
+    exp = (100.0 * np.mean(ranks <= 1), 100.0 * np.mean(ranks <= 5), 100.0 * np.mean(ranks <= 10), np.floor(np.median(ranks)),
+           ranks.mean(), (1.0 / ranks).mean(), (1.0 / ranks).mean())
+    np.testing.assert_allclose(got, exp, rtol=1e-13, atol=0)
+    with pytest.raises(RuntimeError):
+        ops.rank_metrics(dev(np.array([1, 0, 3], np.int32), torch.int32))
