@@ -138,6 +138,8 @@ def main():
     ap.add_argument('--workload', default='c4_40kx10k')
     ap.add_argument('--precision', default='fp16')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of HIP-graph replays')
+    ap.add_argument('--profile-steps', type=int, default=5, help='eager steps (after the timed region) for per-kernel events')
     ap.add_argument('--seed', type=int, default=1237)
     args = ap.parse_args()
 
@@ -168,21 +170,51 @@ def main():
     prof = LaunchProfiler()
     ops.profiler = prof
 
-    def step(timed):
+    metrics_pinned = torch.zeros(8, dtype=torch.float64).pin_memory()
+
+    def step(timed, async_metrics=False):
         timer.enabled = timed
         prof.enabled = timed
         timer.start()
-        return evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer)
+        return evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer,
+                                metrics_out=metrics_pinned if async_metrics else None)
 
-    for _ in range(args.warmup):
+    # The timed region replays ONE captured HIP graph per step (single GPU): the step is ~15 launches of 10-1000 us
+    # each, and eager Python issue (~0.3 ms per step) would otherwise sit on the critical path of every step because
+    # the step ends with a host sync (the 7 metrics).  Collectives are not captured: N > 1 runs eager.
+    graph = None
+    use_graph = (world == 1) and not args.no_graph
+    for _ in range(max(1, args.warmup)):
         res = step(False)
     torch.cuda.synchronize()
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                res = step(False, async_metrics=True)
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print('warning: HIP graph capture failed (%s); timing eager launches' % e, file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+            res = step(False)
+
+    def timed_step():
+        if graph is not None:
+            graph.replay()
+            torch.cuda.current_stream().synchronize()     # the step's result (7 metrics) is on the host
+            return None
+        return step(graph is None and world > 1 or args.no_graph)
+
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        res = step(True)
+        r = timed_step()
+        if r is not None:
+            res = r
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -192,16 +224,27 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if graph is not None:
+        final_metrics = tuple(metrics_pinned[:7].tolist())
+        # per-kernel durations: the same kernels on the same data, launched eagerly with events around each launch
+        for _ in range(args.profile_steps):
+            res = step(True)
+        torch.cuda.synchronize()
+        prof_steps = args.profile_steps
+    else:
+        final_metrics = res['metrics']
+        prof_steps = args.steps
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         pairs = float(Nt) * Nv
-        stages = {k: t / c for k, (t, c) in timer.totals().items()}     # ms per step per stage (this rank)
+        stages = {k: t / c for k, (t, c) in timer.totals().items()}
+        res = dict(res, metrics=final_metrics)     # ms per step per stage (this rank)
         # ---- roofline of the dominant kernel: ALGORITHMIC work (SURVEY.md section 8d / DESIGN.md) / measured launch time
         K = heads * d
         nvl, ntl = v1 - v0, t1 - t0
         feat, L = 512, 4
-        launches = {k: (t / args.steps, c // args.steps) for k, (t, c) in prof.totals().items()}   # ms per step, launches per step
+        launches = {k: (t / prof_steps, c // prof_steps) for k, (t, c) in prof.totals().items()}   # ms per step, launches per step
         x3 = 3 if args.precision.endswith('x3') else 1
         work = {   # entry point -> (bound, algorithmic units per step on this rank, peak, unit scale)
             'fc_act_bn': ('mfma', 2.0 * feat * K * L * (ntl + nvl), MFMA_PEAK_TFLOPS['f32'], 1e12, 'TFLOP/s'),
@@ -243,7 +286,8 @@ def main():
             'data': 'synthetic',
             'config': {'workload': '%s: %d texts x %d videos, 4+4 features of 512-d, %d head(s) x d=%d' % (args.workload, Nt, Nv, heads, d),
                        'parallelism': 'video-row shards x%d, all-gather of text operand' % world if world > 1 else 'single GPU',
-                       'scores': 'fp32 S materialised in HBM'},
+                       'scores': 'fp32 S materialised in HBM',
+                       'launch': 'HIP graph replay' if graph is not None else 'eager'},
             'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6]},
             'stages_ms': {k: round(v, 4) for k, v in stages.items()},
             'kernels': per_kernel,

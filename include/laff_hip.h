@@ -157,6 +157,9 @@ int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const
  * rank1[Nq] device int32, 1-based.  out7 (host) = r1, r5, r10, medr, meanr, mir, mAP.  Reduced on the device
  * (one small kernel), 56 bytes copied back; synchronises the stream. */
 int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, double out7[7]);
+/* Same, without synchronising: out8 is PINNED HOST memory (8 doubles: the 7 metrics + an error flag word, non-zero if a
+ * rank < 1 was seen); valid once the stream has been synchronised.  Capturable in a HIP graph. */
+int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, double* out8_pinned_host);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,7 @@ SIGNATURES = {
     'laff_rank_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I]),
     'laff_v2t_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _I, _P]),
     'laff_rank_metrics': (C.c_int, [_P, _P, _I, C.POINTER(C.c_double)]),
+    'laff_rank_metrics_async': (C.c_int, [_P, _P, _I, _P]),
 }
 
 _lib = None

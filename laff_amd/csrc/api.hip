@@ -157,7 +157,7 @@ int laff_fc_act_bn_grouped(laff_ctx* ctx, const laff_fc_problem* problems, int c
             laff::GemmArgs a;
             bool aligned;
             if (int rc = fc_problem_args(problems[i], a, aligned, "laff_fc_act_bn_grouped")) return rc;
-            if (problems[i].N == 0 || laff::staging_kind(a, 4, aligned, 128) != kind) continue;
+            if (problems[i].N == 0 || laff::staging_kind(a, 4, aligned) != kind) continue;
             ga.p[ga.count++] = a;
             if (ga.count == laff::MAX_GROUP) {
                 HIP_TRY(laff::launch_gemm_nt_grouped_f32(ga, kind, ctx->stream));
@@ -316,6 +316,20 @@ int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv,
     const int bf16 = (precision == LAFF_PREC_BF16 || precision == LAFF_PREC_BF16X3);
     DeviceGuard g(ctx->device);
     HIP_TRY(laff::launch_row_dot_gt(T, V, Nt, Nv, K, bf16, is_x3(precision) ? 1 : 0, scale, gt_col, col0, s_gt, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, double* out8) {
+    CHECK_CTX(ctx);
+    if (!rank1 || !out8) return fail(LAFF_E_ARG, "laff_rank_metrics_async: null argument");
+    if (Nq < 1) return fail(LAFF_E_SHAPE, "laff_rank_metrics_async: Nq=%d", Nq);
+    DeviceGuard g(ctx->device);
+    if (!ctx->d_metrics) {
+        HIP_TRY(hipMalloc((void**)&ctx->d_metrics, 8 * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
+    }
+    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, ctx->d_metrics, (int*)(ctx->d_metrics + 7), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out8, ctx->d_metrics, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return LAFF_OK;
 }
 

@@ -9,13 +9,19 @@
 //     R = T[Nt,K], C = V[Nv,K], fp16/bf16 MFMA (v_mfma_f32_32x32x16_*), 1 or 3 passes (hi/lo split),
 //     epilogue scale (+ fused ground-truth rank count, predictor.py:232-244 in count form).
 //
-// Structure (v1): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 2x2 MFMA
-// tiles of 32x32), K-step = 128 bytes per row (64 halves / 32 floats), two LDS stages of 32 KiB
-// (2 workgroups per CU), operands staged global -> LDS with 16-byte direct-to-LDS loads
-// (global_load_lds_dwordx4).  The LDS image is lane-linear, so the bank-conflict swizzle is applied to the
-// per-lane SOURCE address and undone on the ds_read_b128 side (chunk ^= (row>>1)&7 inside each 128-byte row).
-// The MFMA "A" operand is fed from C rows and "B" from R rows so that each lane ends up with 4 consecutive
-// output columns of one output row per accumulator quad -> 16-byte global stores.
+// Structure: WR x WC waves per workgroup, each wave owns (WM*32) x (WN*32) outputs as WM x WN MFMA tiles of 32x32.
+// K-step = 128 bytes per row (64 halves / 32 floats); two LDS stages; operands staged global -> LDS with 16-byte
+// direct-to-LDS loads (global_load_lds_dwordx4) issued from inline asm with hand-counted vmcnt (hipcc would otherwise
+// put `s_waitcnt vmcnt(0)` in front of every K-step's first ds_read).  The LDS image is lane-linear, so the
+// bank-conflict swizzle is applied to the per-lane SOURCE address and undone on the ds_read_b128 side
+// (chunk ^= (row>>1)&7 inside each 128-byte row: SQ_LDS_BANK_CONFLICT = 0 measured).
+// The MFMA "A" operand is fed from C rows and "B" from R rows so that each lane ends up with 4 consecutive output
+// columns of one output row per accumulator quad.
+//
+// Two configurations are instantiated:
+//   Cfg128 : 2x2 waves of 64x64   -> 128x128 tile, 256 threads, 64 KiB LDS, 2 workgroups / CU   (fp32 FC, small problems)
+//   Cfg256 : 2x4 waves of 128x64  -> 256x256 tile, 512 threads, 128 KiB LDS, 1 workgroup / CU   (16-bit similarity:
+//            half the operand bytes per flop through the per-CU load path, 3/4 of the LDS reads per MFMA)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,24 +29,37 @@
 
 namespace laff {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0, 0, 0, 0};
 
-constexpr int TILE = 128;          // output tile edge
-// ROWB = bytes of K per row per K-step (template parameter: 128 or 64); one operand tile = TILE*ROWB bytes
+constexpr int ROWB = 128;   // bytes of K per row per K-step
+
+template <int WM_, int WN_, int WR_, int WC_>
+struct Cfg {
+    static constexpr int WM = WM_, WN = WN_, WR = WR_, WC = WC_;
+    static constexpr int TR = WR * WM * 32, TC = WC * WN * 32;     // output tile
+    static constexpr int THREADS = 64 * WR * WC;
+    static constexpr int OPB_R = TR * ROWB, OPB_C = TC * ROWB, STAGEB = OPB_R + OPB_C;
+    static constexpr int SMEM = 2 * STAGEB;
+    static constexpr int ITR = TR * 8 / THREADS, ITC = TC * 8 / THREADS;   // 16-byte chunks per thread per stage
+    static constexpr int WPS = (THREADS / 64) * ((160 * 1024) / SMEM) / 4;  // waves per SIMD the LDS budget admits
+    static_assert(WN == 2, "the epilogue slab assumes 64 output columns per wave");
+    static_assert(THREADS / 64 * 32 * 68 * 4 <= SMEM, "epilogue slabs must fit in the operand ring");
+};
+using Cfg128 = Cfg<2, 2, 2, 2>;
+using Cfg256 = Cfg<4, 2, 2, 4>;
 
 template <int MODE> struct ModeTraits;
 template <> struct ModeTraits<GEMM_F32> { static constexpr int ESZ = 4; };
 template <> struct ModeTraits<GEMM_F16> { static constexpr int ESZ = 2; };
 template <> struct ModeTraits<GEMM_BF16> { static constexpr int ESZ = 2; };
 
-// tanh / sigmoid on the hardware exp2 + rcp (v_exp_f32, v_rcp_f32: ~1 ulp each): |error| <= ~2e-7 absolute, checked
-// against tanhf in tests/test_gpu_kernels.py.  ocml's tanhf costs ~100 instructions per value, which at 64 outputs
-// per lane is as long as the tile's whole fp32 MFMA stream.
+// tanh / sigmoid on the hardware exp2 + rcp (v_exp_f32, v_rcp_f32: ~1 ulp each): |error| <= ~2.4e-7 absolute (measured
+// against tanhf over [-12, 12]).  ocml's tanhf costs ~100 instructions per value, which at 64 outputs per lane is as
+// long as the tile's whole fp32 MFMA stream.
 __device__ __forceinline__ float fast_tanh(float x) {
     const float t = __builtin_amdgcn_exp2f(x * 2.885390081777927f);     // e^(2x); inf / 0 saturate correctly
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
@@ -57,30 +76,25 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
-// ---- staging ----------------------------------------------------------------------------------------------
-// One operand tile = 128 rows x ROWB/16 chunks of 16 B.  LDS slot p (16-B units) = row*CPR + cs holds source chunk
-// c = cs ^ swz(row) of that row; swz spreads each ds_read_b128 lane group over all 16 slots of the 256-B bank row:
-// ROWB=128: (row>>1)&7 (2 rows per bank row), ROWB=64: (row>>2)&3 (4 rows per bank row).
-template <bool GLDS, int ROWB>
-__device__ __forceinline__ void stage_operand(const char* __restrict__ base, int row0, int nrows, long ldb /*bytes*/,
-                                              long kbyte0, long kbytes_valid /*bytes of K in this segment*/,
-                                              char* lds_op, unsigned lds_op_addr, int tid) {
-    constexpr int CPR = ROWB / 16;               // 16-byte chunks per row
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// ---- staging, generic paths (STG 0: through registers, element-wise K bounds; STG 1: LDS-DMA with per-step address
+// arithmetic, 16-byte K granularity).  One operand tile = ROWS x 8 chunks of 16 B; LDS slot p = row*8 + cs holds
+// source chunk swz(row, cs).
+template <int STG, int ROWS, int THREADS>
+__device__ __forceinline__ void stage_operand(const char* __restrict__ base, int row0, int nrows, long ldb, long kbyte0,
+                                              long kbytes_valid, char* lds_op, unsigned lds_op_addr, int tid) {
 #pragma unroll
-    for (int it = 0; it < TILE * CPR / 256; ++it) {
-        const int p = it * 256 + tid;
-        const int row = p / CPR;
-        const int cs = p % CPR;
-        const int c = ROWB == 128 ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
+    for (int it = 0; it < ROWS * 8 / THREADS; ++it) {
+        const int p = it * THREADS + tid;
+        const int row = p >> 3, cs = p & 7;
+        const int c = swz(row, cs);
         int gr = row0 + row;
         gr = gr < nrows ? gr : nrows - 1;        // clamp: garbage rows are never stored
         const long kb = kbyte0 + (long)c * 16;
-        if constexpr (GLDS) {
+        if constexpr (STG == 1) {
             const char* src = (kb + 16 <= kbytes_valid) ? base + (long)gr * ldb + kb : (const char*)g_zero16;
-            // LDS-DMA: 16 B per lane land at (wave-uniform M0 base) + lane*16.  Issued from inline asm so that hipcc
-            // neither counts it nor forces `s_waitcnt vmcnt(0)` in front of every ds_read (it cannot prove the DMA
-            // targets the other ring slot); completion is tracked by hand with counted vmcnt in the main loop.
-            const unsigned dst = lds_op_addr + (unsigned)(it * 256 + (tid & ~63)) * 16u;
+            const unsigned dst = lds_op_addr + (unsigned)(it * THREADS + (tid & ~63)) * 16u;
             unsigned keep;
             asm volatile(
                 "s_mov_b32 %0, m0\n\t"
@@ -92,7 +106,6 @@ __device__ __forceinline__ void stage_operand(const char* __restrict__ base, int
                 : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
                 : "memory");
         } else {
-            // generic path: element-wise bounds (K tail / unaligned rows), through registers
             uint32_t v[4] = {0, 0, 0, 0};
             const char* rowp = base + (long)gr * ldb;
 #pragma unroll
@@ -109,16 +122,15 @@ __device__ __forceinline__ void stage_operand(const char* __restrict__ base, int
     }
 }
 
-template <int ROWB>
 __device__ __forceinline__ uint4 lds_frag(const char* lds_op, int row, int chunk) {
-    const int cs = ROWB == 128 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
-    return *(const uint4*)(lds_op + row * ROWB + cs * 16);
+    return *(const uint4*)(lds_op + row * ROWB + swz(row, chunk) * 16);
 }
 
-// Fast staging (K*esz %% ROWB == 0, operand < 4 GiB): the per-lane part of every source address is a 32-bit byte
-// offset computed ONCE per tile; a K-step only advances a scalar base (saddr form), so the loop carries no VALU.
+// ---- staging, fast path (STG 2: K bytes a multiple of the K-step, operand below 4 GiB): the per-lane part of every
+// source address is a 32-bit byte offset computed ONCE per tile; a K-step only advances a scalar base (saddr form), so
+// the main loop carries no address VALU.  LDS-DMA lands 16 B per lane at (wave-uniform M0 base) + lane*16.
 template <int IT>
-__device__ __forceinline__ void glds_issue(const unsigned (&off)[IT], unsigned long long sbase, unsigned dst0) {
+__device__ __forceinline__ void glds_issue(const unsigned (&off)[IT], unsigned long long sbase, unsigned dst0, unsigned stride) {
     static_assert(IT == 2 || IT == 4, "");
     unsigned keep;
     const unsigned d0 = __builtin_amdgcn_readfirstlane(dst0);
@@ -131,8 +143,8 @@ __device__ __forceinline__ void glds_issue(const unsigned (&off)[IT], unsigned l
             "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
-            : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(sbase), "s"(d0), "s"(d0 + 4096u), "s"(d0 + 8192u),
-              "s"(d0 + 12288u)
+            : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(sbase), "s"(d0), "s"(d0 + stride),
+              "s"(d0 + 2 * stride), "s"(d0 + 3 * stride)
             : "memory");
     } else {
         asm volatile(
@@ -141,12 +153,11 @@ __device__ __forceinline__ void glds_issue(const unsigned (&off)[IT], unsigned l
             "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
-            : "v"(off[0]), "v"(off[1]), "s"(sbase), "s"(d0), "s"(d0 + 4096u)
+            : "v"(off[0]), "v"(off[1]), "s"(sbase), "s"(d0), "s"(d0 + stride)
             : "memory");
     }
 }
 
-// ---- kernel -----------------------------------------------------------------------------------------------
 // blockIdx -> linear tile id such that each XCD (block b runs on XCD b % 8) works on a contiguous chunk of tiles
 // and neighbouring tiles share operand panels in that XCD's L2 (bijective for any nb).
 __device__ __forceinline__ int xcd_remap(int bid, int nb) {
@@ -154,20 +165,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int MODE, int STG, int NS, int ROWB>
+// ---- one output tile ----------------------------------------------------------------------------------------------
+template <int MODE, int STG, typename CF>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char* smem) {
     constexpr int ESZ = ModeTraits<MODE>::ESZ;
-    constexpr int OPB = TILE * ROWB, STAGEB = 2 * OPB;
+    constexpr int WM = CF::WM, WN = CF::WN, THREADS = CF::THREADS;
     constexpr bool GLDS = STG != 0;
-    constexpr int IT = TILE * (ROWB / 16) / 256;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / CF::WC, wc = wave % CF::WC;
     const int l31 = lane & 31, hh = lane >> 5;
 
     // groups of 8 tile rows swept along c: 8 R panels + 8 C panels live in L2 at a time
-    const int tiles_r = (a.nR + TILE - 1) / TILE, tiles_c = (a.nC + TILE - 1) / TILE;
+    const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
     const int gsz_full = 8 * tiles_c;
     const int grp = lin / gsz_full;
     const int first_r = grp * 8;
@@ -175,85 +186,79 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
     const int in_grp = lin - grp * gsz_full;
     const int tile_r = first_r + in_grp % gsz;
     const int tile_c = in_grp / gsz;
-    const int r0 = tile_r * TILE, c0 = tile_c * TILE;
+    const int r0 = tile_r * CF::TR, c0 = tile_c * CF::TC;
 
     const long ldRb = (long)a.ldR * ESZ, ldCb = (long)a.ldC * ESZ;
     const long Kb = (long)a.K * ESZ;
     const int kt_per_seg = (int)((Kb + ROWB - 1) / ROWB);
     const int nkt = kt_per_seg * a.nseg;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
-    // per-lane source offsets of this tile (fast path): slot p = it*256 + tid -> (row, swizzled chunk)
-    unsigned offR[IT], offC[IT];
+    // per-lane source offsets of this tile (fast path): slot p = it*THREADS + tid -> (row, swizzled chunk)
+    unsigned offR[CF::ITR], offC[CF::ITC];
     if constexpr (STG == 2) {
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            constexpr int CPR = ROWB / 16;
-            const int p = it * 256 + tid;
-            const int row = p / CPR, cs = p % CPR;
-            const int c = ROWB == 128 ? (cs ^ ((row >> 1) & 7)) : (cs ^ ((row >> 2) & 3));
-            offR[it] = (unsigned)min(r0 + row, a.nR - 1) * (unsigned)ldRb + (unsigned)c * 16u;
-            offC[it] = (unsigned)min(c0 + row, a.nC - 1) * (unsigned)ldCb + (unsigned)c * 16u;
+        for (int it = 0; it < CF::ITR; ++it) {
+            const int p = it * THREADS + tid, row = p >> 3;
+            offR[it] = (unsigned)min(r0 + row, a.nR - 1) * (unsigned)ldRb + (unsigned)swz(row, p & 7) * 16u;
+        }
+#pragma unroll
+        for (int it = 0; it < CF::ITC; ++it) {
+            const int p = it * THREADS + tid, row = p >> 3;
+            offC[it] = (unsigned)min(c0 + row, a.nC - 1) * (unsigned)ldCb + (unsigned)swz(row, p & 7) * 16u;
         }
     }
     auto stage = [&](int kt, int buf) {
         const int seg = kt / kt_per_seg;
         const long kb0 = (long)(kt - seg * kt_per_seg) * ROWB;
-        char* s = smem + buf * STAGEB;
-        const unsigned sa = lds0 + (unsigned)buf * STAGEB;
+        char* s = smem + buf * CF::STAGEB;
+        const unsigned sa = lds0 + (unsigned)buf * CF::STAGEB;
         if constexpr (STG == 2) {
             const unsigned wbase = (unsigned)(tid & ~63) * 16u;
-            glds_issue<IT>(offR, (unsigned long long)((const char*)a.R + a.segR[seg] + kb0), sa + wbase);
-            glds_issue<IT>(offC, (unsigned long long)((const char*)a.C + a.segC[seg] + kb0), sa + OPB + wbase);
+            glds_issue<CF::ITR>(offR, (unsigned long long)((const char*)a.R + a.segR[seg] + kb0), sa + wbase, THREADS * 16u);
+            glds_issue<CF::ITC>(offC, (unsigned long long)((const char*)a.C + a.segC[seg] + kb0), sa + CF::OPB_R + wbase,
+                                THREADS * 16u);
         } else {
-            stage_operand<GLDS, ROWB>((const char*)a.R + a.segR[seg], r0, a.nR, ldRb, kb0, Kb, s, sa, tid);
-            stage_operand<GLDS, ROWB>((const char*)a.C + a.segC[seg], c0, a.nC, ldCb, kb0, Kb, s + OPB, sa + OPB, tid);
+            stage_operand<STG, CF::TR, THREADS>((const char*)a.R + a.segR[seg], r0, a.nR, ldRb, kb0, Kb, s, sa, tid);
+            stage_operand<STG, CF::TC, THREADS>((const char*)a.C + a.segC[seg], c0, a.nC, ldCb, kb0, Kb, s + CF::OPB_R,
+                                                sa + CF::OPB_R, tid);
         }
     };
-    constexpr int LOADS = 2 * (TILE * (ROWB / 16) / 256);    // LDS-DMA instructions per thread per stage
 
-    // ring of NS stages, prefetch distance NS-1, ONE barrier per K-step:
-    //   wait(stage kt landed) -> barrier -> issue stage kt+NS-1 into the slot read in step kt-1 -> compute(kt)
-#pragma unroll
-    for (int p = 0; p < NS - 1; ++p)
-        if (p < nkt) stage(p, p);
-
+    // ring of 2 stages, ONE barrier per K-step:
+    //   wait(stage kt landed) -> barrier -> issue stage kt+1 into the slot read in step kt-1 -> compute(kt)
+    stage(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         if constexpr (GLDS) {
-            // loads retire in order: stage kt is done when at most (stages issued after it) * LOADS remain
-            const int after = min(nkt - 1 - kt, NS - 2);
-            if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-            else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         } else {
             __syncthreads();
         }
-        if (kt + NS - 1 < nkt) stage(kt + NS - 1, (kt + NS - 1) % NS);
-        const char* sR = smem + (kt % NS) * STAGEB;
-        const char* sC = sR + OPB;
+        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        const char* sR = smem + (kt & 1) * CF::STAGEB;
+        const char* sC = sR + CF::OPB_R;
 #pragma unroll
         for (int ks = 0; ks < ROWB / 32; ++ks) {
             const int chunk = 2 * ks + hh;
-            uint4 fc[2], fr[2];
+            uint4 fc[WN], fr[WM];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                fc[t] = lds_frag<ROWB>(sC, wc * 64 + t * 32 + l31, chunk);
-                fr[t] = lds_frag<ROWB>(sR, wr * 64 + t * 32 + l31, chunk);
-            }
+            for (int t = 0; t < WN; ++t) fc[t] = lds_frag(sC, wc * (WN * 32) + t * 32 + l31, chunk);
 #pragma unroll
-            for (int tr = 0; tr < 2; ++tr)
+            for (int t = 0; t < WM; ++t) fr[t] = lds_frag(sR, wr * (WM * 32) + t * 32 + l31, chunk);
 #pragma unroll
-                for (int tc = 0; tc < 2; ++tc) {
+            for (int tr = 0; tr < WM; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < WN; ++tc) {
                     if constexpr (MODE == GEMM_F32) {
                         const float* pa = (const float*)&fc[tc];
                         const float* pb = (const float*)&fr[tr];
@@ -275,18 +280,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
     // ---- epilogue ----------------------------------------------------------------------------------------------
     // Accumulator layout: lane (l31, hh) holds out[row l31 of the 32-row block][4 consecutive columns] per register
     // quad.  The per-column epilogue (scale, bias, activation, folded BN, ground-truth patch + rank count) runs in
-    // that layout; the tile then goes through a wave-private LDS slab (32 x 64 fp32, row pitch 68 words) so that
+    // that layout; the block then goes through a wave-private LDS slab (32 x 64 fp32, row pitch 68 words) so that
     // every global store instruction writes 4 rows x 256 contiguous bytes instead of 64 scattered 16-byte pieces.
     __syncthreads();                                   // every wave is done reading the operand ring
     constexpr int PITCH = 68;
-    static_assert(4 * 32 * PITCH * 4 <= NS * 2 * TILE * ROWB, "epilogue slabs must fit in the operand ring");
     float* slab = (float*)smem + wave * (32 * PITCH);
     const bool vec_ok = a.out && ((a.ldo & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0);
     const bool has_epi = a.bias || a.bn_scale || a.act;
-    const int cw0 = c0 + wc * 64;                      // first output column of this wave
+    const int cw0 = c0 + wc * (WN * 32);               // first output column of this wave
 #pragma unroll
-    for (int tr = 0; tr < 2; ++tr) {
-        const int rbase = r0 + wr * 64 + tr * 32;
+    for (int tr = 0; tr < WM; ++tr) {
+        const int rbase = r0 + wr * (WM * 32) + tr * 32;
         const int rr = rbase + l31;
         const bool row_ok = rr < a.nR;
         int cnt = 0;
@@ -297,7 +301,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
             sg = a.s_gt[rr];
         }
 #pragma unroll
-        for (int tc = 0; tc < 2; ++tc) {
+        for (int tc = 0; tc < WN; ++tc) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = tc * 32 + 8 * q + 4 * hh;          // column inside the wave's 64
@@ -307,7 +311,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
                 for (int e = 0; e < 4; ++e) v[e] = acc[tr][tc][4 * q + e] * a.scale;
                 if (has_epi) {
                     float bb[4] = {0, 0, 0, 0}, ss[4] = {1, 1, 1, 1}, hs[4] = {0, 0, 0, 0};
-                    if (cc + 3 < a.nC) {          // per-column parameters as 16-byte loads (rows are 16-byte aligned)
+                    if (cc + 3 < a.nC) {          // per-column parameters as 16-byte loads
                         if (a.bias) *(float4*)bb = *(const float4*)(a.bias + cc);
                         if (a.bn_scale) {
                             *(float4*)ss = *(const float4*)(a.bn_scale + cc);
@@ -366,27 +370,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
     }
 }
 
-constexpr int waves_per_simd(int ns, int rowb) {    // workgroups per CU by LDS (160 KiB), capped at 4 by the VGPR budget
-    const int by_lds = (160 * 1024) / (ns * 2 * TILE * rowb);
-    return by_lds > 4 ? 4 : (by_lds < 1 ? 1 : by_lds);
-}
-
-template <int MODE, int STG, int NS, int ROWB>
-__global__ __launch_bounds__(256, waves_per_simd(NS, ROWB)) void gemm_nt_kernel(GemmArgs a) {
+template <int MODE, int STG, typename CF>
+__global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tiles_r = (a.nR + TILE - 1) / TILE, tiles_c = (a.nC + TILE - 1) / TILE;
-    gemm_tile<MODE, STG, NS, ROWB>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), smem);
+    const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
+    gemm_tile<MODE, STG, CF>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), smem);
 }
 
 // several independent problems (the FC projections of all fused features) in ONE launch: fills the chip where a
 // single 10k-row projection has only 316 tiles for 512 workgroup slots, and removes 7 launch boundaries.
-template <int MODE, int STG, int NS, int ROWB>
-__global__ __launch_bounds__(256, waves_per_simd(NS, ROWB)) void gemm_nt_grouped_kernel(GroupedGemmArgs g) {
+template <int MODE, int STG, typename CF>
+__global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_grouped_kernel(GroupedGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lin = xcd_remap(blockIdx.x, g.tile_start[g.count]);
     int p = 0;
     while (p + 1 < g.count && lin >= g.tile_start[p + 1]) ++p;     // wave-uniform scalar search
-    gemm_tile<MODE, STG, NS, ROWB>(g.p[p], lin - g.tile_start[p], smem);
+    gemm_tile<MODE, STG, CF>(g.p[p], lin - g.tile_start[p], smem);
 }
 
 template <typename K>
@@ -395,38 +394,44 @@ static hipError_t set_smem(K kernel, int smem) {
     return hipSuccess;
 }
 
-template <int MODE, int STG, int NS, int ROWB>
+template <int MODE, int STG, typename CF>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t st) {
-    const int tiles_r = (a.nR + TILE - 1) / TILE, tiles_c = (a.nC + TILE - 1) / TILE;
-    const long nb = (long)tiles_r * tiles_c;
+    const long nb = (long)((a.nR + CF::TR - 1) / CF::TR) * ((a.nC + CF::TC - 1) / CF::TC);
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
-    constexpr int smem = NS * 2 * TILE * ROWB;
-    hipError_t e = set_smem(gemm_nt_kernel<MODE, STG, NS, ROWB>, smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gemm_nt_kernel<MODE, STG, NS, ROWB>), dim3((unsigned)nb), dim3(256), smem, st, a);
+    static bool attr_set = false;          // once per instantiation; also keeps the call out of HIP-graph captures
+    if (!attr_set) {
+        hipError_t e = set_smem(gemm_nt_kernel<MODE, STG, CF>, CF::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<MODE, STG, CF>), dim3((unsigned)nb), dim3(CF::THREADS), CF::SMEM, st, a);
     return hipGetLastError();
 }
 
 // staging kind of one problem: 0 = through registers (unaligned rows / ragged K), 1 = LDS-DMA with per-step address
-// arithmetic (ragged K tail), 2 = LDS-DMA fast path (K bytes a multiple of the K-step, operands below 4 GiB)
-int staging_kind(const GemmArgs& a, int esz, bool aligned, int rowb) {
+// arithmetic (K tail in whole 16-byte chunks), 2 = LDS-DMA fast path (K bytes a multiple of the K-step, operands < 4 GiB)
+int staging_kind(const GemmArgs& a, int esz, bool aligned) {
     if (!aligned) return 0;
     const long long Kb = (long long)a.K * esz;
     const long long spanR = (long long)a.nR * a.ldR * esz, spanC = (long long)a.nC * a.ldC * esz;
-    if (Kb % rowb == 0 && spanR < (1ll << 32) && spanC < (1ll << 32)) return 2;
+    if (Kb % ROWB == 0 && spanR < (1ll << 32) && spanC < (1ll << 32)) return 2;
     return 1;
 }
 
-int g_gemm_variant = 0;   // reserved tuning knob (LAFF_GEMM_VARIANT)
+int g_gemm_variant = 0;   // tuning knob LAFF_GEMM_VARIANT: 128 / 256 force the tile configuration of the 16-bit GEMM
 
 template <int MODE>
 static hipError_t launch_m(const GemmArgs& a, bool aligned, hipStream_t st) {
-    const int esz = ModeTraits<MODE>::ESZ;
-    const int rowb = 128;
-    const int stg = staging_kind(a, esz, aligned, rowb);
-    if (stg == 0) return launch_t<MODE, 0, 2, 128>(a, st);
-    if (stg == 1) return launch_t<MODE, 1, 2, 128>(a, st);
-    return launch_t<MODE, 2, 2, 128>(a, st);
+    const int stg = staging_kind(a, ModeTraits<MODE>::ESZ, aligned);
+    if (stg == 0) return launch_t<MODE, 0, Cfg128>(a, st);
+    if (stg == 1) return launch_t<MODE, 1, Cfg128>(a, st);
+    if constexpr (MODE != GEMM_F32) {
+        // big tiles when there are enough of them to fill 256 CUs a few times over
+        const long tiles256 = (long)((a.nR + 255) / 256) * ((a.nC + 255) / 256);
+        const bool big = g_gemm_variant == 256 || (g_gemm_variant != 128 && tiles256 >= 512);
+        if (big) return launch_t<MODE, 2, Cfg256>(a, st);
+    }
+    return launch_t<MODE, 2, Cfg128>(a, st);
 }
 
 template <int STG>
@@ -434,12 +439,11 @@ static hipError_t launch_grouped_t(GroupedGemmArgs& g, hipStream_t st) {
     long nb = 0;
     for (int i = 0; i < g.count; ++i) {
         g.tile_start[i] = (int)nb;
-        nb += (long)((g.p[i].nR + TILE - 1) / TILE) * ((g.p[i].nC + TILE - 1) / TILE);
+        nb += (long)((g.p[i].nR + Cfg128::TR - 1) / Cfg128::TR) * ((g.p[i].nC + Cfg128::TC - 1) / Cfg128::TC);
     }
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
     g.tile_start[g.count] = (int)nb;
-    constexpr int smem = 2 * 2 * TILE * 128;
-    hipLaunchKernelGGL((gemm_nt_grouped_kernel<GEMM_F32, STG, 2, 128>), dim3((unsigned)nb), dim3(256), smem, st, g);
+    hipLaunchKernelGGL((gemm_nt_grouped_kernel<GEMM_F32, STG, Cfg128>), dim3((unsigned)nb), dim3(Cfg128::THREADS), Cfg128::SMEM, st, g);
     return hipGetLastError();
 }
 

@@ -40,7 +40,7 @@ struct GroupedGemmArgs {
 
 hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool aligned, hipStream_t st);
 hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int staging, hipStream_t st);
-int staging_kind(const GemmArgs& a, int esz, bool aligned, int rowb);
+int staging_kind(const GemmArgs& a, int esz, bool aligned);
 extern int g_gemm_variant;
 
 constexpr int MAX_L = 8;

@@ -31,6 +31,7 @@ class HipBackend:
 
     def __init__(self, model, precision='fp16'):
         self.model, self.precision = model, precision
+        ops.ctx_prepare_metrics(next(model.parameters()).device)     # scratch allocation outside any graph capture
 
     def embed_both(self, vis_feats, txt_feats):
         """Single-rank shortcut: both towers' FC projections in one grouped launch."""
@@ -71,9 +72,12 @@ class HipBackend:
     def metrics(self, ranks):
         return ops.rank_metrics(ranks)
 
+    def metrics_async(self, ranks, out_pinned):
+        ops.rank_metrics_async(ranks, out_pinned)
+
 
 def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
-                     timer=None, want_scores=True):
+                     timer=None, want_scores=True, metrics_out=None):
     """One pass of the hot path on this rank's shards.  gt: (Nt,) int32 GLOBAL video column of every text (replicated).
 
     Returns dict(S_local (Nt, v1-v0), col0, ranks (Nt,), metrics)."""
@@ -134,6 +138,10 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
             dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
         ranks = count + 1
         mark('rank')
-        metrics = compute.metrics(ranks) if want_metrics else None
+        metrics = None
+        if metrics_out is not None:
+            compute.metrics_async(ranks, metrics_out)     # no host sync: the caller reads metrics_out after one
+        elif want_metrics:
+            metrics = compute.metrics(ranks)
         mark('metrics')
     return {'S_local': S_local, 'col0': v0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb}

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, Plane, check)
 
-__all__ = ['fc_act_bn', 'fc_act_bn_grouped', 'row_dot_gt', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['fc_act_bn', 'fc_act_bn_grouped', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -279,3 +279,28 @@ def rank_metrics(rank1):
     lib, h = _context(rank1.device)
     check(lib.laff_rank_metrics(h, _ptr(rank1.contiguous()), rank1.numel(), out))
     return tuple(out)
+
+
+def rank_metrics_async(rank1, out_pinned):
+    """Launch the metrics reduction and the 64-byte D2H copy without synchronising (HIP-graph capturable).
+    out_pinned: pinned CPU float64 tensor of 8; after a stream sync [:7] are the metrics, [7] != 0 flags a rank < 1."""
+    _dev(rank1, 'rank1', torch.int32)
+    if out_pinned.dtype != torch.float64 or out_pinned.numel() < 8 or not out_pinned.is_pinned():
+        raise ValueError('out_pinned must be a pinned float64 tensor of >= 8 elements')
+    lib, h = _context(rank1.device)
+    if ('metrics', h.value) not in _ctx:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('call ops.ctx_prepare_metrics(device) before capturing a graph (it allocates scratch)')
+        ctx_prepare_metrics(rank1.device)
+    check(lib.laff_rank_metrics_async(h, _ptr(rank1.contiguous()), rank1.numel(), C.c_void_p(out_pinned.data_ptr())))
+
+
+def ctx_prepare_metrics(device):
+    """Allocate the ctx's metrics scratch outside any graph capture (hipMalloc is not capturable)."""
+    lib, h = _context(device)
+    key = ('metrics', h.value)
+    if key not in _ctx:
+        r = torch.ones(1, dtype=torch.int32, device=device)
+        out = (C.c_double * 7)()
+        check(lib.laff_rank_metrics(h, _ptr(r), 1, out))
+        _ctx[key] = True
