@@ -136,7 +136,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c4_40kx10k')
-    ap.add_argument('--precision', default='fp16')
+    ap.add_argument('--precision', default='fp16', help='similarity GEMM operands: fp16 | fp16x3 | bf16x3 | bf16')
+    ap.add_argument('--fc-precision', default='fp16x3', help="FC projections: fp32 (fp32 MFMA) | fp16x3 (exact fp16 hi/lo split)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of HIP-graph replays')
     ap.add_argument('--profile-steps', type=int, default=5, help='eager steps (after the timed region) for per-kernel events')
@@ -156,6 +157,8 @@ def main():
 
     from laff_amd import synth
     from laff_amd.dist import HipBackend, evaluate_sharded, shard_bounds
+    import laff_amd.model.model as M
+    M.FC_PRECISION = args.fc_precision
     Nt, Nv, heads, d, frames = synth.WORKLOADS[args.workload]
     model = synth.build_model(heads, d, dev, frames=frames, seed=args.seed)
     vis, txt, gt, lens = synth.make_features(Nt, Nv, dev, frames=frames, seed=args.seed)
@@ -247,7 +250,9 @@ def main():
         launches = {k: (t / prof_steps, c // prof_steps) for k, (t, c) in prof.totals().items()}   # ms per step, launches per step
         x3 = 3 if args.precision.endswith('x3') else 1
         work = {   # entry point -> (bound, algorithmic units per step on this rank, peak, unit scale)
-            'fc_act_bn': ('mfma', 2.0 * feat * K * L * (ntl + nvl), MFMA_PEAK_TFLOPS['f32'], 1e12, 'TFLOP/s'),
+            'fc_act_bn': ('mfma', 2.0 * feat * K * L * (ntl + nvl) * (3 if args.fc_precision == 'fp16x3' else 1),
+                          MFMA_PEAK_TFLOPS['f16' if args.fc_precision == 'fp16x3' else 'f32'], 1e12, 'TFLOP/s'),
+            'split_rows': ('hbm', (4.0 + 4.0) * feat * L * (ntl + nvl), HBM_PEAK_GBS, 1e9, 'GB/s'),
             'fuse': ('hbm', 4.0 * (ntl + nvl) * K * (L + 1), HBM_PEAK_GBS, 1e9, 'GB/s'),
             'pack_rows': ('hbm', (4.0 + 2.0 * (2 if x3 == 3 else 1)) * (ntl + nvl) * K, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'rank_count': ('hbm', 4.0 * Nt * nvl, HBM_PEAK_GBS, 1e9, 'GB/s'),
@@ -282,7 +287,7 @@ def main():
         line = {
             'metric': 'text-video cosine pairs/sec', 'value': pairs / elapsed * args.steps, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
-            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32 towers + %s similarity' % args.precision,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32 towers (FC on %s) + %s similarity' % ('fp32 MFMA' if args.fc_precision == 'fp32' else 'fp16 hi/lo split x3 MFMA', args.precision),
             'data': 'synthetic',
             'config': {'workload': '%s: %d texts x %d videos, 4+4 features of 512-d, %d head(s) x d=%d' % (args.workload, Nt, Nv, heads, d),
                        'parallelism': 'video-row shards x%d, all-gather of text operand' % world if world > 1 else 'single GPU',

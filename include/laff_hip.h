@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 1
+#define LAFF_ABI_VERSION 2
 
 enum {
     LAFF_OK = 0,
@@ -87,6 +87,21 @@ typedef struct {
     float* Y; int ldy;
 } laff_fc_problem;
 int laff_fc_act_bn_grouped(laff_ctx* ctx, const laff_fc_problem* problems /*host array*/, int count);
+
+/* a1 on the 16-bit matrix pipe with fp32-class accuracy ("fp16x3"): both operands are split once into exact fp16
+ * hi + lo parts with a per-row power-of-two scale (laff_split_rows); the GEMM accumulates lo*hi + hi*lo + hi*hi in fp32
+ * (fp16 x fp16 products are exact in fp32; the dropped lo*lo term is 2^-22 relative) and the epilogue undoes the scales.
+ * 3 MFMA passes at the 2.5 PF fp16 rate instead of one at the 157 TF fp32 rate. */
+int laff_split_rows_bytes(int N, int K, size_t* out);            /* bytes of the [2][N][Kp] fp16 operand, Kp = ceil(K/64)*64 */
+int laff_split_rows(laff_ctx* ctx, const float* X, int N, int K, int ldx, void* out_hi_lo, float* rscale /*[N]*/);
+typedef struct {
+    const void* Xs; const float* x_rscale; int N, Dk;          /* laff_split_rows(X[N,Dk]) */
+    const void* Ws; const float* w_rscale;                      /* laff_split_rows(W[D,Dk]) */
+    const float* bias; const float* bn_scale; const float* bn_shift;
+    int D, act;
+    float* Y; int ldy;
+} laff_fc_split_problem;
+int laff_fc_act_bn_split_grouped(laff_ctx* ctx, const laff_fc_split_problem* problems /*host array*/, int count);
 
 /* ---- a2-a6: stack + Multi_head_MyApply_Attention / Attention_1 / JustAverage ----------------------------
  * (model/model.py:1858-1876, :1663-1705; model/Attention.py:508-531, :78-105)

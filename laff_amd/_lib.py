@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'liblaff_hip.so')
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Plane(C.Structure):
@@ -22,6 +22,12 @@ class FcProblem(C.Structure):
                 ('Y', C.c_void_p), ('ldy', C.c_int)]
 
 
+class FcSplitProblem(C.Structure):
+    _fields_ = [('Xs', C.c_void_p), ('x_rscale', C.c_void_p), ('N', C.c_int), ('Dk', C.c_int), ('Ws', C.c_void_p),
+                ('w_rscale', C.c_void_p), ('bias', C.c_void_p), ('bn_scale', C.c_void_p), ('bn_shift', C.c_void_p),
+                ('D', C.c_int), ('act', C.c_int), ('Y', C.c_void_p), ('ldy', C.c_int)]
+
+
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     'laff_abi_version': (C.c_int, []),
@@ -32,6 +38,9 @@ SIGNATURES = {
     'laff_device_info': (C.c_int, [_P, C.POINTER(_I)]),
     'laff_fc_act_bn': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I]),
     'laff_fc_act_bn_grouped': (C.c_int, [_P, C.POINTER(FcProblem), _I]),
+    'laff_split_rows_bytes': (C.c_int, [_I, _I, C.POINTER(C.c_size_t)]),
+    'laff_split_rows': (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
+    'laff_fc_act_bn_split_grouped': (C.c_int, [_P, C.POINTER(FcSplitProblem), _I]),
     'laff_fuse': (C.c_int, [_P, C.POINTER(Plane), _I, _I, _I, _I, _P, _P, _P, C.c_uint, _P, _P]),
     'laff_frame_fuse': (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, C.c_uint, _P]),
     'laff_packed_bytes': (C.c_int, [_I, _I, _I, C.POINTER(C.c_size_t)]),

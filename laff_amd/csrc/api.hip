@@ -169,6 +169,60 @@ int laff_fc_act_bn_grouped(laff_ctx* ctx, const laff_fc_problem* problems, int c
     return LAFF_OK;
 }
 
+int laff_split_rows_bytes(int N, int K, size_t* out) {
+    if (!out || N < 0 || K < 1) return fail(LAFF_E_ARG, "laff_split_rows_bytes: bad args");
+    const size_t Kp = (size_t)(K + 63) / 64 * 64;
+    *out = 2 * (size_t)N * Kp * 2;
+    return LAFF_OK;
+}
+
+int laff_split_rows(laff_ctx* ctx, const float* X, int N, int K, int ldx, void* out, float* rscale) {
+    CHECK_CTX(ctx);
+    if (!X || !out || !rscale) return fail(LAFF_E_ARG, "laff_split_rows: null argument");
+    if (N < 0 || K < 1 || ldx < K) return fail(LAFF_E_SHAPE, "laff_split_rows: bad shape N=%d K=%d ldx=%d", N, K, ldx);
+    if (!aligned16(out)) return fail(LAFF_E_ALIGN, "laff_split_rows: out must be 16-byte aligned");
+    if (N == 0) return LAFF_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_split_rows(X, N, K, ldx, (K + 63) / 64 * 64, out, rscale, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_fc_act_bn_split_grouped(laff_ctx* ctx, const laff_fc_split_problem* problems, int count) {
+    CHECK_CTX(ctx);
+    if (!problems || count < 0) return fail(LAFF_E_ARG, "laff_fc_act_bn_split_grouped: bad problem list");
+    DeviceGuard g(ctx->device);
+    laff::GroupedGemmArgs ga{};
+    for (int i = 0; i < count; ++i) {
+        const laff_fc_split_problem& q = problems[i];
+        if (!q.Xs || !q.Ws || !q.x_rscale || !q.w_rscale || !q.Y) return fail(LAFF_E_ARG, "laff_fc_act_bn_split_grouped: problem %d has a null operand", i);
+        if (q.N < 0 || q.Dk < 1 || q.D < 1 || q.ldy < q.D) return fail(LAFF_E_SHAPE, "laff_fc_act_bn_split_grouped: problem %d bad shape", i);
+        if (q.act < LAFF_ACT_NONE || q.act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fc_act_bn_split_grouped: bad act %d", q.act);
+        if ((q.bn_scale == nullptr) != (q.bn_shift == nullptr)) return fail(LAFF_E_ARG, "laff_fc_act_bn_split_grouped: bn_scale/bn_shift must come together");
+        if (!aligned16(q.Xs) || !aligned16(q.Ws) || (q.bias && !aligned16(q.bias)) || (q.bn_scale && (!aligned16(q.bn_scale) || !aligned16(q.bn_shift))))
+            return fail(LAFF_E_ALIGN, "laff_fc_act_bn_split_grouped: problem %d: 16-byte alignment", i);
+        const int Kp = (q.Dk + 63) / 64 * 64;
+        if ((long long)q.N * Kp * 4 >= (1ll << 32) || (long long)q.D * Kp * 4 >= (1ll << 32))
+            return fail(LAFF_E_UNSUPPORTED, "laff_fc_act_bn_split_grouped: problem %d: packed operand exceeds 4 GiB", i);
+        if (q.N == 0) continue;
+        laff::GemmArgs a{};
+        a.R = q.Xs; a.C = q.Ws; a.nR = q.N; a.nC = q.D; a.K = Kp; a.ldR = Kp; a.ldC = Kp;
+        a.nseg = 3;                                   // lo*hi, hi*lo (small terms first), hi*hi
+        a.segR[0] = (long)q.N * Kp * 2; a.segC[0] = 0;
+        a.segR[1] = 0;                  a.segC[1] = (long)q.D * Kp * 2;
+        a.segR[2] = 0;                  a.segC[2] = 0;
+        a.out = q.Y; a.ldo = q.ldy; a.scale = 1.0f;
+        a.row_scale = q.x_rscale; a.col_scale = q.w_rscale;
+        a.bias = q.bias; a.bn_scale = q.bn_scale; a.bn_shift = q.bn_shift; a.act = q.act;
+        ga.p[ga.count++] = a;
+        if (ga.count == laff::MAX_GROUP) {
+            HIP_TRY(laff::launch_gemm_nt_grouped_f16(ga, ctx->stream));
+            ga.count = 0;
+        }
+    }
+    if (ga.count) HIP_TRY(laff::launch_gemm_nt_grouped_f16(ga, ctx->stream));
+    return LAFF_OK;
+}
+
 int laff_fuse(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
               const float* gw, unsigned flags, float* E, float* attn_w) {
     CHECK_CTX(ctx);

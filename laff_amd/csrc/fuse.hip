@@ -448,6 +448,61 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
     }
 }
 
+// ---- exact-product operand split for the FC GEMM on the 16-bit matrix pipe --------------------------------------
+// x*s = hi + lo with s = 2^(9 - floor(log2 max|x_row|)) (row maximum lands in [512, 1024): no fp16 overflow for any input
+// magnitude, lo stays normal down to 2^-34 of the row maximum), hi = fp16(x*s), lo = fp16(x*s - hi).  fp16 x fp16
+// products are exact in fp32, so hi*hi' + hi*lo' + lo*hi' reproduces the fp32 product to ~2^-22 relative.
+// out: [2][N][Kp] fp16 (hi plane, lo plane), columns >= K zero filled; rscale[n] = 1/s (a power of two: exact).
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, int N, int K, int ldx, int Kp,
+                                                         _Float16* __restrict__ out, float* __restrict__ rscale) {
+    const int lane = threadIdx.x & 63;
+    const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* src = X + n * ldx;
+    const bool vec = !(K & 3) && !(ldx & 3) && !((uintptr_t)X & 15);
+    float m = 0.f;
+    if (vec) {
+        for (int c = lane * 4; c < K; c += 256) {
+            const float4 v = *(const float4*)(src + c);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (int c = lane; c < K; c += 64) m = fmaxf(m, fabsf(src[c]));
+    }
+    m = wave_max(m);
+    int e = 0;
+    if (m > 0.f && m < INFINITY) e = ilogbf(m);
+    const float s = ldexpf(1.0f, 9 - e);
+    if (lane == 0) rscale[n] = ldexpf(1.0f, e - 9);
+    _Float16* hi = out + n * Kp;
+    _Float16* lo = out + (long)N * Kp + n * Kp;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    for (int c = lane * 4; c < Kp; c += 256) {       // Kp % 64 == 0, rows of the packed operand are 128-byte aligned
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && c + 3 < K) {
+            *(float4*)v = *(const float4*)(src + c);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < K) v[j] = src[c + j];
+        }
+        h4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = v[j] * s;
+            h[j] = (_Float16)t;
+            l[j] = (_Float16)(t - (float)h[j]);
+        }
+        *(h4*)(hi + c) = h;
+        *(h4*)(lo + c) = l;
+    }
+}
+
+hipError_t launch_split_rows(const float* X, int N, int K, int ldx, int Kp, void* out, float* rscale, hipStream_t st) {
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, X, N, K, ldx, Kp, (_Float16*)out, rscale);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,
                             int precision, void* out, hipStream_t st) {
     const long items = (long)N * H;

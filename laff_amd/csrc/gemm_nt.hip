@@ -300,6 +300,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
             gt = a.gt_col[rr] - a.col0;
             sg = a.s_gt[rr];
         }
+        const float rscl = (a.row_scale && row_ok) ? a.scale * a.row_scale[rr] : a.scale;
 #pragma unroll
         for (int tc = 0; tc < WN; ++tc) {
 #pragma unroll
@@ -308,7 +309,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
                 const int cc = cw0 + cl;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[tr][tc][4 * q + e] * a.scale;
+                for (int e = 0; e < 4; ++e) v[e] = acc[tr][tc][4 * q + e] * rscl;
+                if (a.col_scale) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= (cc + e < a.nC) ? a.col_scale[cc + e] : 1.0f;
+                }
                 if (has_epi) {
                     float bb[4] = {0, 0, 0, 0}, ss[4] = {1, 1, 1, 1}, hs[4] = {0, 0, 0, 0};
                     if (cc + 3 < a.nC) {          // per-column parameters as 16-byte loads
@@ -445,6 +450,32 @@ static hipError_t launch_grouped_t(GroupedGemmArgs& g, hipStream_t st) {
     g.tile_start[g.count] = (int)nb;
     hipLaunchKernelGGL((gemm_nt_grouped_kernel<GEMM_F32, STG, Cfg128>), dim3((unsigned)nb), dim3(Cfg128::THREADS), Cfg128::SMEM, st, g);
     return hipGetLastError();
+}
+
+template <typename CF>
+static hipError_t launch_grouped_f16_t(GroupedGemmArgs& g, hipStream_t st) {
+    long nb = 0;
+    for (int i = 0; i < g.count; ++i) {
+        g.tile_start[i] = (int)nb;
+        nb += (long)((g.p[i].nR + CF::TR - 1) / CF::TR) * ((g.p[i].nC + CF::TC - 1) / CF::TC);
+    }
+    if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
+    g.tile_start[g.count] = (int)nb;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = set_smem(gemm_nt_grouped_kernel<GEMM_F16, 2, CF>, CF::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_grouped_kernel<GEMM_F16, 2, CF>), dim3((unsigned)nb), dim3(CF::THREADS), CF::SMEM, st, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_nt_grouped_f16(GroupedGemmArgs& g, hipStream_t st) {
+    long t256 = 0;
+    for (int i = 0; i < g.count; ++i) t256 += (long)((g.p[i].nR + 255) / 256) * ((g.p[i].nC + 255) / 256);
+    const bool big = g_gemm_variant == 256 || (g_gemm_variant != 128 && t256 >= 512);
+    return big ? launch_grouped_f16_t<Cfg256>(g, st) : launch_grouped_f16_t<Cfg128>(g, st);
 }
 
 hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int stg, hipStream_t st) {

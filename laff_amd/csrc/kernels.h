@@ -19,6 +19,8 @@ struct GemmArgs {
     float* out;           // [nR, ldo] or null
     int ldo;
     float scale;
+    const float* row_scale;   // optional per-output-row / per-output-column factors (operand split scales)
+    const float* col_scale;
     // FC epilogue
     const float* bias;
     const float* bn_scale;
@@ -40,6 +42,7 @@ struct GroupedGemmArgs {
 
 hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool aligned, hipStream_t st);
 hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int staging, hipStream_t st);
+hipError_t launch_gemm_nt_grouped_f16(GroupedGemmArgs& g, hipStream_t st);   // fast staging only (packed operands)
 int staging_kind(const GemmArgs& a, int esz, bool aligned);
 extern int g_gemm_variant;
 
@@ -73,6 +76,7 @@ struct FrameArgs {
 };
 hipError_t launch_frame_fuse(const FrameArgs& a, hipStream_t st);
 
+hipError_t launch_split_rows(const float* X, int N, int K, int ldx, int Kp, void* out, float* rscale, hipStream_t st);
 hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,
                             int precision, void* out, hipStream_t st);
 

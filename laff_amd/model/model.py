@@ -27,6 +27,18 @@ from .Attention import Attention_1, JustAverage, Multi_head_MyApply_Attention
 
 device = torch.device('cuda')
 float16 = False
+#: arithmetic of the FC projections: 'fp32' (v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 FMA chain) or 'fp16x3'
+#: (exact fp16 hi/lo operand split, 3 MFMA passes at the fp16 rate, ~2^-22 relative per product)
+FC_PRECISION = 'fp32'
+
+
+def run_fc(pending):
+    """Launch every queued FC projection as one grouped GEMM."""
+    if FC_PRECISION == 'fp16x3':
+        return ops.fc_act_bn_split_grouped(pending)
+    if FC_PRECISION != 'fp32':
+        raise ValueError("FC_PRECISION must be 'fp32' or 'fp16x3'")
+    return ops.fc_act_bn_grouped(pending)
 
 
 def _initialize_weights(m):
@@ -118,6 +130,16 @@ class TransformNet(nn.Module):
             shift = (shift + extra_shift).contiguous()
         return scale, shift
 
+    def weight_split(self):
+        """fp16 hi/lo split of fc1.weight for FC_PRECISION == 'fp16x3', cached until the weight changes."""
+        if FC_PRECISION != 'fp16x3':
+            return None
+        w = self.fc1.weight
+        key = (w.data_ptr(), w._version)
+        if getattr(self, '_w_split', None) is None or self._w_split[0] != key:
+            self._w_split = (key, ops.split_rows(w.detach()))
+        return self._w_split[1]
+
     def plane(self, x, heads=1, extra_shift=None, pending=None):
         """(src, tile, scale, shift) for laff_fuse.  With an FC the projection either runs now or, when `pending`
         (a list) is given, is appended to it so that the caller launches all features' GEMMs as one grouped kernel."""
@@ -125,11 +147,11 @@ class TransformNet(nn.Module):
         x = to_device_and_float16(x)
         scale, shift = self.bn_affine(extra_shift)
         if self.fc1 is not None:
-            prob = dict(x=x, weight=self.fc1.weight.detach(),
+            prob = dict(x=x, weight=self.fc1.weight.detach(), weight_split=self.weight_split(),
                         bias=self.fc1.bias.detach() if self.fc1.bias is not None else None,
                         bn_scale=scale, bn_shift=shift, activation=self.activation_name)
             if pending is None:
-                y = ops.fc_act_bn_grouped([prob])[0]
+                y = run_fc([prob])[0]
             else:
                 y = prob['out'] = torch.empty((x.shape[0], self.out_features), device=x.device, dtype=torch.float32)
                 pending.append(prob)
@@ -201,7 +223,7 @@ class VisMutiTransformNet(nn.Module):
         heads = self.opt.multi_head_attention['heads']
         pending = []
         planes = self.planes(vis_input, pending=pending)
-        ops.fc_act_bn_grouped(pending)
+        run_fc(pending)
         return {name: _materialise(p, heads, self.common_space_dim)
                 for name, p in zip(self.vis_net_space_dict.keys(), planes)}
 
@@ -233,7 +255,7 @@ class VisMutiTransformNetAddAttnetion(nn.Module):
     def forward(self, vis_input, txt_emb=None, vis_frame_feat_dict_input=None):
         pending = []
         finish = self.prepare(vis_input, pending=pending)
-        ops.fc_act_bn_grouped(pending)
+        run_fc(pending)
         return finish()
 
     def get_attention_weight(self, vis_input, txt_emb=None):
@@ -335,7 +357,7 @@ class MultiScaleTxtEncoderAttention(nn.Module):
     def forward(self, caption_feat_dict, visual_emb=None, task3=False):
         pending = []
         finish = self.prepare(caption_feat_dict, pending, task3)
-        ops.fc_act_bn_grouped(pending)
+        run_fc(pending)
         return finish()
 
     def get_attention_weight(self, caption_feat_dict, visual_emb=None):
@@ -397,7 +419,7 @@ class VisMutiTransformNetPlusFrameFeat(nn.Module):
     def forward(self, vis_input, vis_frame_feat_dict_input, txt_emb=None):
         pending = []
         finish = self.prepare(vis_input, vis_frame_feat_dict_input, pending)
-        ops.fc_act_bn_grouped(pending)
+        run_fc(pending)
         return finish()
 
     def prepare(self, vis_input, vis_frame_feat_dict_input=None, pending=None):

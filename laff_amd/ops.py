@@ -10,9 +10,9 @@ import torch
 
 from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
-                   FcProblem, Plane, check)
+                   FcProblem, FcSplitProblem, Plane, check)
 
-__all__ = ['fc_act_bn', 'fc_act_bn_grouped', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -123,6 +123,61 @@ def fc_act_bn_grouped(problems):
         keep.append((x, w, vecs))
     lib, h = _context(problems[0]['x'].device)
     _call('fc_act_bn', lib.laff_fc_act_bn_grouped, h, arr, len(problems))
+    return outs
+
+
+class SplitOperand:
+    """fp16 hi/lo split of an fp32 matrix (laff_split_rows): buffer [2][N][Kp] + per-row reciprocal scales."""
+
+    def __init__(self, buf, rscale, N, K):
+        self.buf, self.rscale, self.N, self.K = buf, rscale, N, K
+
+
+def split_rows(x):
+    x, ldx = _rows(x, 'x')
+    N, K = x.shape
+    lib, h = _context(x.device)
+    nbytes = C.c_size_t()
+    check(lib.laff_split_rows_bytes(N, K, C.byref(nbytes)))
+    buf = torch.empty((max(nbytes.value, 16),), device=x.device, dtype=torch.uint8)
+    rscale = torch.empty((max(N, 1),), device=x.device, dtype=torch.float32)
+    _call('split_rows', lib.laff_split_rows, h, _ptr(x), N, K, ldx, _ptr(buf), _ptr(rscale))
+    return SplitOperand(buf, rscale, N, K)
+
+
+def fc_act_bn_split_grouped(problems):
+    """fc_act_bn_grouped on the fp16 matrix pipe with fp32-class accuracy.  problems: dicts with x (fp32 tensor or
+    SplitOperand), weight_split (SplitOperand of W), optional bias / bn_scale / bn_shift / activation / out."""
+    if not problems:
+        return []
+    arr = (FcSplitProblem * len(problems))()
+    outs, keep = [], []
+    dev = problems[0]['weight_split'].buf.device
+    for i, q in enumerate(problems):
+        xs = q['x'] if isinstance(q['x'], SplitOperand) else split_rows(q['x'])
+        ws = q['weight_split']
+        if xs.K != ws.K:
+            raise ValueError('problem %d: x has %d columns, weight %d' % (i, xs.K, ws.K))
+        N, D = xs.N, ws.N
+        vecs = []
+        for nm in ('bias', 'bn_scale', 'bn_shift'):
+            t = q.get(nm)
+            if t is not None:
+                _dev(t, nm)
+                if t.numel() != D or not t.is_contiguous():
+                    raise ValueError('%s must be a contiguous vector of %d' % (nm, D))
+            vecs.append(t)
+        out = q.get('out')
+        if out is None:
+            out = torch.empty((N, D), device=dev, dtype=torch.float32)
+        y, ldy = _rows(out, 'out')
+        arr[i] = FcSplitProblem(xs.buf.data_ptr(), xs.rscale.data_ptr(), N, xs.K, ws.buf.data_ptr(), ws.rscale.data_ptr(),
+                                *[t.data_ptr() if t is not None else None for t in vecs], D, ACT[q.get('activation')],
+                                y.data_ptr(), ldy)
+        outs.append(out)
+        keep.append((xs, ws, vecs))
+    lib, h = _context(dev)
+    _call('fc_act_bn', lib.laff_fc_act_bn_split_grouped, h, arr, len(problems))
     return outs
 
 

@@ -24,7 +24,8 @@ def embed(model, vis_feats, txt_feats):
     pending = []                                  # all FC projections of both towers -> ONE grouped launch
     fin_v = model.vis_net.prepare(vis, frame_dict, pending)
     fin_t = model.txt_net.prepare(cap, pending)
-    ops.fc_act_bn_grouped(pending)
+    from .model.model import run_fc
+    run_fc(pending)
     return fin_v(), fin_t()
 
 

@@ -59,8 +59,11 @@ def build_model(heads, d, device, frames=0, feat_dim=512, seed=1234):
     return model
 
 
-def make_features(Nt, Nv, device, frames=0, feat_dim=512, seed=1234, noise=0.5):
+def make_features(Nt, Nv, device, frames=0, feat_dim=512, seed=1234, noise=None):
     """Returns (vis_feats{name: (Nv, D_k)} or frame tensors, txt_feats{key: (Nt, D_k)}, gt int32 (Nt,), lens|None)."""
+    import os
+    if noise is None:
+        noise = float(os.environ.get('LAFF_SYNTH_NOISE', '1.6'))
     g = torch.Generator(device=device).manual_seed(seed)
 
     def randn(*shape):

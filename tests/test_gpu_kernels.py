@@ -321,3 +321,29 @@ def test_rank_metrics_device_vs_numpy(n):
     np.testing.assert_allclose(got, exp, rtol=1e-13, atol=0)
     with pytest.raises(RuntimeError):
         ops.rank_metrics(dev(np.array([1, 0, 3], np.int32), torch.int32))
+
+
+@pytest.mark.parametrize('N,Dk,D', [(1, 4, 4), (33, 96, 512), (130, 1030, 260), (300, 512, 512), (70, 77, 130), (5, 3981, 200)])
+def test_fc_split_fp16x3_vs_fp64(N, Dk, D):
+    """FC on the fp16 pipe with the exact hi/lo split: same tolerance as the fp32-MFMA path, incl. huge / tiny rows."""
+    from laff_amd import ops
+    g = rnd(N + Dk + D)
+    x = g.normal(0, 1, (N, Dk)).astype(np.float32)
+    x[0] *= 3e4            # beyond the fp16 range without the per-row scale
+    if N > 2:
+        x[1] *= 1e-6
+        x[2] = 0
+    W = (g.normal(0, 1, (D, Dk)) / np.sqrt(Dk)).astype(np.float32)
+    b = g.normal(0, 0.1, D).astype(np.float32)
+    sc = g.uniform(0.5, 1.5, D).astype(np.float32)
+    sh = g.normal(0, 0.1, D).astype(np.float32)
+    ws = ops.split_rows(dev(W))
+    for act in (None, 'tanh'):
+        y = ops.fc_act_bn_split_grouped([dict(x=dev(x), weight_split=ws, bias=dev(b), bn_scale=dev(sc), bn_shift=dev(sh),
+                                              activation=act)])[0]
+        pre = x.astype(np.float64) @ W.astype(np.float64).T + b
+        ref = (np.tanh(pre) if act else pre) * sc + sh
+        scale = 1.0 if act else np.maximum(1.0, np.abs(pre).max(axis=1, keepdims=True))
+        assert float(np.max(np.abs(y.cpu().numpy() - ref) / scale)) <= 2e-5
+        y32 = ops.fc_act_bn(dev(x), dev(W), dev(b), dev(sc), dev(sh), act)
+        assert float(np.max(np.abs((y - y32).cpu().numpy()) / scale)) <= 2e-5

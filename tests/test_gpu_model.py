@@ -158,3 +158,25 @@ def test_single_head_model_runs_2d():
     assert maxdiff(te, O.fuse_tower(specs, att, 1)) <= 5e-6
     S = model.get_txt2vis_matrix(te, ve, precision='fp32')
     assert maxdiff(S, O.txt2vis_matrix(te.cpu().numpy(), ve.cpu().numpy())) <= 2e-6
+
+
+def test_laff_towers_golden_fp16x3_fc(golden):
+    """The towers with FC_PRECISION = 'fp16x3' stay inside the embedding tolerance of the fp32 path."""
+    import laff_amd.model.model as M
+    g = golden('laff_towers')
+    M.FC_PRECISION = 'fp16x3'
+    try:
+        for c in g.json('cases'):
+            k = c['key']
+            cfg = make_config(c['vid_dims'], c['txt_dims'], c['D'], c['H'], 'LAFF', c['vis_no_transform'],
+                              c['txt_no_transform'], with_ave=c['with_ave'], mul=c['mul'], batch_norm=c['batch_norm'])
+            model = get_model('LAFF', DEV, cfg).eval()
+            load_sd(model, g.sub(k + '/sd/'))
+            ve = model.vis_net({n: t(g[k + '/vis/' + n]) for n in c['vid_dims']})
+            cap = {'caption': ['x'] * 24}
+            cap.update({TXT_KEY[n]: t(v) for n, v in g.sub(k + '/txt/').items()})
+            te = model.txt_net(cap)
+            assert maxdiff(ve, g[k + '/vis_emb']) <= 5e-6
+            assert maxdiff(te, g[k + '/txt_emb']) <= 5e-6
+    finally:
+        M.FC_PRECISION = 'fp32'
