@@ -208,7 +208,7 @@ def main():
             graph.replay()
             torch.cuda.current_stream().synchronize()     # the step's result (7 metrics) is on the host
             return None
-        return step(graph is None and world > 1 or args.no_graph)
+        return step(True)        # eager: per-launch events are recorded inside the timed region
 
     if world > 1:
         dist.barrier()
