@@ -133,17 +133,13 @@ static int fc_problem_args(const laff_fc_problem& q, laff::GemmArgs& a, bool& gl
     return LAFF_OK;
 }
 
+int laff_fc_act_bn_grouped(laff_ctx* ctx, const laff_fc_problem* problems, int count);
+
 int laff_fc_act_bn(laff_ctx* ctx, const float* X, int N, int Dk, int ldx, const float* W, int ldw, const float* bias,
                    const float* bn_scale, const float* bn_shift, int D, int act, float* Y, int ldy) {
     CHECK_CTX(ctx);
     laff_fc_problem q{X, N, Dk, ldx, W, ldw, bias, bn_scale, bn_shift, D, act, Y, ldy};
-    laff::GemmArgs a;
-    bool glds;
-    if (int rc = fc_problem_args(q, a, glds, "laff_fc_act_bn")) return rc;
-    if (N == 0) return LAFF_OK;
-    DeviceGuard g(ctx->device);
-    HIP_TRY(laff::launch_gemm_nt(a, laff::GEMM_F32, glds, ctx->stream));
-    return LAFF_OK;
+    return laff_fc_act_bn_grouped(ctx, &q, 1);
 }
 
 int laff_fc_act_bn_grouped(laff_ctx* ctx, const laff_fc_problem* problems, int count) {
@@ -319,6 +315,7 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
     }
     a.out = S; a.ldo = lds; a.scale = scale;
     a.gt_col = gt_col; a.col0 = col0; a.s_gt = s_gt; a.count = gt_col ? count : nullptr;
+    if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
     int mode = laff::GEMM_F32;
     if (precision == LAFF_PREC_FP16 || precision == LAFF_PREC_FP16X3) mode = laff::GEMM_F16;
     if (precision == LAFF_PREC_BF16 || precision == LAFF_PREC_BF16X3) mode = laff::GEMM_BF16;

@@ -67,15 +67,6 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
-__device__ __forceinline__ float act_apply(float v, int act) {
-    switch (act) {
-        case 1: return fast_tanh(v);
-        case 2: return fmaxf(v, 0.0f);
-        case 3: return fast_sigmoid(v);
-        default: return v;
-    }
-}
-
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 // ---- staging, generic paths (STG 0: through registers, element-wise K bounds; STG 1: LDS-DMA with per-step address
@@ -165,8 +156,127 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// ---- epilogue ----------------------------------------------------------------------------------------------------
+// Accumulator layout: lane (l31, hh) holds out[row l31 of the 32-row block][4 consecutive columns] per register quad.
+// The per-column epilogue runs in that layout; the block then goes through a wave-private LDS slab (32 x 64 fp32, row
+// pitch 68 words) so that every global store instruction writes 4 rows x 256 contiguous bytes instead of 64 scattered
+// 16-byte pieces.  EPI_SIM: scale (+ ground-truth patch and rank count); EPI_FC: row/column scales, bias, activation,
+// folded BatchNorm.  FULL = interior tile with 16-byte aligned output: no bounds logic at all (a first version with
+// per-element bounds and per-element activation switches compiled to 12k lines of branches and cost 37 % of the tile).
+enum { EPI_SIM = 0, EPI_FC = 1 };
+
+template <int EPI, bool FULL, typename CF>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM][CF::WN], int r0, int c0, int wr, int wc,
+                                         int wave, int lane, char* smem) {
+    constexpr int WM = CF::WM, WN = CF::WN, PITCH = 68;
+    const int l31 = lane & 31, hh = lane >> 5;
+    float* slab = (float*)smem + wave * (32 * PITCH);
+    const int cw0 = c0 + wc * (WN * 32);               // first output column of this wave
+    const bool counting = EPI == EPI_SIM && a.count != nullptr;
+#pragma unroll
+    for (int tr = 0; tr < WM; ++tr) {
+        const int rbase = r0 + wr * (WM * 32) + tr * 32;
+        const int rr = rbase + l31;
+        const bool row_ok = FULL || rr < a.nR;
+        int cnt = 0;
+        int gt = -1;
+        float sg = 0.0f;
+        if (counting && row_ok) {
+            gt = a.gt_col[rr] - a.col0;
+            sg = a.s_gt[rr];
+        }
+        float rscl = a.scale;
+        if (EPI == EPI_FC && a.row_scale && row_ok) rscl *= a.row_scale[rr];
+#pragma unroll
+        for (int tc = 0; tc < WN; ++tc) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = tc * 32 + 8 * q + 4 * hh;          // column inside the wave's 64
+                const int cc = cw0 + cl;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[tr][tc][4 * q + e] * rscl;
+                if constexpr (EPI == EPI_FC) {
+                    float cs[4] = {1, 1, 1, 1}, bb[4] = {0, 0, 0, 0}, ss[4] = {1, 1, 1, 1}, hs[4] = {0, 0, 0, 0};
+                    if (FULL || cc + 3 < a.nC) {          // per-column parameters as 16-byte loads
+                        if (a.col_scale) *(float4*)cs = *(const float4*)(a.col_scale + cc);
+                        if (a.bias) *(float4*)bb = *(const float4*)(a.bias + cc);
+                        if (a.bn_scale) {
+                            *(float4*)ss = *(const float4*)(a.bn_scale + cc);
+                            *(float4*)hs = *(const float4*)(a.bn_shift + cc);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (cc + e < a.nC) {
+                                if (a.col_scale) cs[e] = a.col_scale[cc + e];
+                                if (a.bias) bb[e] = a.bias[cc + e];
+                                if (a.bn_scale) { ss[e] = a.bn_scale[cc + e]; hs[e] = a.bn_shift[cc + e]; }
+                            }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], cs[e], bb[e]);
+                    if (a.act == 1) {                      // wave-uniform: one scalar branch per quad
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fast_tanh(v[e]);
+                    } else if (a.act == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    } else if (a.act == 3) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fast_sigmoid(v[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ss[e], hs[e]);
+                }
+                if (counting) {
+                    // the ground-truth entry is DEFINED by the pre-pass value s_gt (laff_row_dot_gt); writing it into S keeps
+                    // "rank counted here" == "rank recounted from S" exactly (and excludes it from the count: sg > sg is false)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (cc + e == gt) ? sg : v[e];
+                        const bool in = FULL || (row_ok && cc + e < a.nC);
+                        cnt += (in && v[e] > sg) ? 1 : 0;
+                    }
+                }
+                if (a.out) *(float4*)(slab + l31 * PITCH + cl) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        if (counting) {
+            cnt += __shfl_xor(cnt, 32);
+            if (hh == 0 && row_ok && cnt) atomicAdd(a.count + rr, cnt);
+        }
+        if (a.out) {
+            __builtin_amdgcn_wave_barrier();
+            const int col4 = (lane & 15) * 4;
+            const int gc = cw0 + col4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = (lane >> 4) + 4 * j;
+                const float4 v = *(const float4*)(slab + row * PITCH + col4);
+                const int gr = rbase + row;
+                float* o = a.out + (long)gr * a.ldo + gc;
+                if constexpr (FULL) {
+                    *(float4*)o = v;
+                } else if (gr < a.nR) {
+                    const bool vec_ok = ((a.ldo & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0);
+                    if (vec_ok && gc + 3 < a.nC) {
+                        *(float4*)o = v;
+                    } else {
+                        const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (gc + e < a.nC) o[e] = t[e];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();            // slab is rewritten by the next 32-row block
+        }
+    }
+}
+
 // ---- one output tile ----------------------------------------------------------------------------------------------
-template <int MODE, int STG, typename CF>
+template <int MODE, int STG, typename CF, int EPI>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char* smem) {
     constexpr int ESZ = ModeTraits<MODE>::ESZ;
     constexpr int WM = CF::WM, WN = CF::WN, THREADS = CF::THREADS;
@@ -193,6 +303,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
     const int kt_per_seg = (int)((Kb + ROWB - 1) / ROWB);
     const int nkt = kt_per_seg * a.nseg;
 
+#ifdef LAFF_GEMM_TRACE
+#define TRACE(i) do { if (a.trace && tid == 0) a.trace[(long)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    if (a.trace && tid == 0) a.trace[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(0xf814) /*XCC_ID*/;
+#else
+#define TRACE(i) do {} while (0)
+#endif
+    TRACE(0);
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -235,12 +352,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
 
     // ring of 2 stages, ONE barrier per K-step:
     //   wait(stage kt landed) -> barrier -> issue stage kt+1 into the slot read in step kt-1 -> compute(kt)
+    TRACE(1);
     stage(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         if constexpr (GLDS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (kt == 0) TRACE(2);
+            if (kt == 1) TRACE(3);
         } else {
             __syncthreads();
         }
@@ -277,109 +397,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
         if constexpr (!GLDS) __syncthreads();
     }
 
-    // ---- epilogue ----------------------------------------------------------------------------------------------
-    // Accumulator layout: lane (l31, hh) holds out[row l31 of the 32-row block][4 consecutive columns] per register
-    // quad.  The per-column epilogue (scale, bias, activation, folded BN, ground-truth patch + rank count) runs in
-    // that layout; the block then goes through a wave-private LDS slab (32 x 64 fp32, row pitch 68 words) so that
-    // every global store instruction writes 4 rows x 256 contiguous bytes instead of 64 scattered 16-byte pieces.
+    TRACE(4);
     __syncthreads();                                   // every wave is done reading the operand ring
-    constexpr int PITCH = 68;
-    float* slab = (float*)smem + wave * (32 * PITCH);
-    const bool vec_ok = a.out && ((a.ldo & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0);
-    const bool has_epi = a.bias || a.bn_scale || a.act;
-    const int cw0 = c0 + wc * (WN * 32);               // first output column of this wave
-#pragma unroll
-    for (int tr = 0; tr < WM; ++tr) {
-        const int rbase = r0 + wr * (WM * 32) + tr * 32;
-        const int rr = rbase + l31;
-        const bool row_ok = rr < a.nR;
-        int cnt = 0;
-        int gt = -1;
-        float sg = 0.0f;
-        if (a.count && row_ok) {
-            gt = a.gt_col[rr] - a.col0;
-            sg = a.s_gt[rr];
-        }
-        const float rscl = (a.row_scale && row_ok) ? a.scale * a.row_scale[rr] : a.scale;
-#pragma unroll
-        for (int tc = 0; tc < WN; ++tc) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = tc * 32 + 8 * q + 4 * hh;          // column inside the wave's 64
-                const int cc = cw0 + cl;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[tr][tc][4 * q + e] * rscl;
-                if (a.col_scale) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= (cc + e < a.nC) ? a.col_scale[cc + e] : 1.0f;
-                }
-                if (has_epi) {
-                    float bb[4] = {0, 0, 0, 0}, ss[4] = {1, 1, 1, 1}, hs[4] = {0, 0, 0, 0};
-                    if (cc + 3 < a.nC) {          // per-column parameters as 16-byte loads
-                        if (a.bias) *(float4*)bb = *(const float4*)(a.bias + cc);
-                        if (a.bn_scale) {
-                            *(float4*)ss = *(const float4*)(a.bn_scale + cc);
-                            *(float4*)hs = *(const float4*)(a.bn_shift + cc);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (cc + e < a.nC) {
-                                if (a.bias) bb[e] = a.bias[cc + e];
-                                if (a.bn_scale) { ss[e] = a.bn_scale[cc + e]; hs[e] = a.bn_shift[cc + e]; }
-                            }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(act_apply(v[e] + bb[e], a.act), ss[e], hs[e]);
-                }
-                if (a.count && row_ok) {
-                    // the ground-truth entry is DEFINED by the pre-pass value s_gt (laff_row_dot_gt); writing it into S
-                    // keeps "rank counted here" == "rank recounted from S" exactly
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = cc + e;
-                        if (c == gt) v[e] = sg;
-                        cnt += (c < a.nC && c != gt && v[e] > sg) ? 1 : 0;
-                    }
-                }
-                if (a.out) *(float4*)(slab + l31 * PITCH + cl) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-        if (a.count) {
-            cnt += __shfl_xor(cnt, 32);
-            if (hh == 0 && row_ok && cnt) atomicAdd(a.count + rr, cnt);
-        }
-        if (a.out) {
-            __builtin_amdgcn_wave_barrier();
-            const int col4 = (lane & 15) * 4;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = (lane >> 4) + 4 * j;
-                const float4 v = *(const float4*)(slab + row * PITCH + col4);
-                const int gr = rbase + row, gc = cw0 + col4;
-                if (gr < a.nR) {
-                    float* o = a.out + (long)gr * a.ldo + gc;
-                    if (vec_ok && gc + 3 < a.nC) {
-                        *(float4*)o = v;
-                    } else {
-                        const float t[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (gc + e < a.nC) o[e] = t[e];
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();            // slab is rewritten by the next 32-row block
-        }
-    }
+    TRACE(5);
+    const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
+                      ((((uintptr_t)a.out) & 15) == 0);
+    if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    TRACE(6);
+#undef TRACE
 }
 
 template <int MODE, int STG, typename CF>
 __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
-    gemm_tile<MODE, STG, CF>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), smem);
+    gemm_tile<MODE, STG, CF, EPI_SIM>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), smem);
 }
 
 // several independent problems (the FC projections of all fused features) in ONE launch: fills the chip where a
@@ -390,7 +423,7 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_grouped_kernel(G
     const int lin = xcd_remap(blockIdx.x, g.tile_start[g.count]);
     int p = 0;
     while (p + 1 < g.count && lin >= g.tile_start[p + 1]) ++p;     // wave-uniform scalar search
-    gemm_tile<MODE, STG, CF>(g.p[p], lin - g.tile_start[p], smem);
+    gemm_tile<MODE, STG, CF, EPI_FC>(g.p[p], lin - g.tile_start[p], smem);
 }
 
 template <typename K>

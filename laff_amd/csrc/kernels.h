@@ -31,6 +31,7 @@ struct GemmArgs {
     int col0;
     const float* s_gt;
     int* count;
+    unsigned long long* trace;   // debug (LAFF_GEMM_TRACE build only): 8 timestamps per workgroup
 };
 
 constexpr int MAX_GROUP = 8;
