@@ -125,8 +125,8 @@ def cpu_baseline(workload, sample_nt, sample_nv, heads, d, seed):
     metrics = O.eval_from_positions([[r] for r in ranks])
     dt = time.perf_counter() - t0
     return {'value': sample_nt * sample_nv / dt, 'unit': 'pairs/s', 'cores': os.cpu_count(), 'kind': 'port',
-            'sample': '%dx%d slice of the same synthetic workload, numpy oracle in the reference\'s batch-64 block-loop '
-                      'shape, %.1f s' % (sample_nt, sample_nv, dt),
+            'sample': '%dx%d slice of the same synthetic workload (seed, generator, weights), numpy oracle in the reference\'s '
+                      'batch-64 block-loop shape, %.1f s on the GPU box host' % (sample_nt, sample_nv, dt),
             'r1': metrics[0]}
 
 
@@ -284,6 +284,20 @@ def main():
                     'frac': pk['frac'], 'traffic': None, 'launches_per_step': pk['launches_per_step'],
                     'avg_launch_ms': round(pk['ms_per_step'] / max(1, pk['launches_per_step']), 5)}
         m = res['metrics']
+        agreement = None
+        if world == 1 and not args.no_cpu_baseline and not args.precision.endswith('x3') and args.precision != 'fp32':
+            # outside the timed region: the same embeddings through the strict (hi/lo split, ~1e-7) similarity
+            from laff_amd import ops as _ops
+            Ts = _ops.pack_rows(res['txt_emb'], True, 1e-13, 'fp16x3')
+            Vs = _ops.pack_rows(res['vis_emb'], True, 1e-13, 'fp16x3')
+            sg = _ops.row_dot_gt(Ts, Vs, gt, heads)
+            cs = torch.zeros(Nt, dtype=torch.int32, device=dev)
+            Ss = _ops.sim_gemm(Ts, Vs, heads=heads, gt_col=gt, s_gt=sg, count=cs)
+            ms = _ops.rank_metrics(cs + 1)
+            agreement = {'max_abs_score_diff_vs_fp16x3': float((Ss - res['S_local']).abs().max()),
+                         'identical_ranks_frac': float(((cs + 1) == res['ranks']).float().mean()),
+                         'strict_R@1/5/10/MedR': [ms[0], ms[1], ms[2], ms[3]]}
+            del Ss, Ts, Vs
         line = {
             'metric': 'text-video cosine pairs/sec', 'value': pairs / elapsed * args.steps, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
@@ -293,13 +307,14 @@ def main():
                        'parallelism': 'video-row shards x%d, all-gather of text operand' % world if world > 1 else 'single GPU',
                        'scores': 'fp32 S materialised in HBM',
                        'launch': 'HIP graph replay' if graph is not None else 'eager'},
-            'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6]},
+            'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6],
+                        'vs_strict_similarity': agreement},
             'stages_ms': {k: round(v, 4) for k, v in stages.items()},
             'kernels': per_kernel,
             'roofline': roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            sn, sv = (8000, 2000) if Nt >= 8000 and Nv >= 2000 else (Nt, Nv)
+            sn, sv = (Nt, Nv) if float(Nt) * Nv <= 4.0e8 else (40000, 10000)       # ~10-20 s of host work
             line['cpu_baseline'] = cpu_baseline(args.workload, sn, sv, heads, d, args.seed)
         print(json.dumps(line))
     if world > 1:

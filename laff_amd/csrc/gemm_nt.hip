@@ -305,7 +305,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
 
 #ifdef LAFF_GEMM_TRACE
 #define TRACE(i) do { if (a.trace && tid == 0) a.trace[(long)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
-    if (a.trace && tid == 0) a.trace[(long)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(0xf814) /*XCC_ID*/;
+    if (a.trace && tid == 0)
+        a.trace[(long)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xf814) /*XCC_ID*/ << 32) |
+                                           __builtin_amdgcn_s_getreg(0xf804) /*HW_ID*/;
 #else
 #define TRACE(i) do {} while (0)
 #endif

@@ -173,11 +173,32 @@ __device__ __forceinline__ int block_max(int v, double* sh) {
     return (int)t;
 }
 
+__device__ __forceinline__ int block_sum_int(int v, int* sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    return t;
+}
+
 __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, double* __restrict__ out7,
                                                             int* __restrict__ err) {
     __shared__ double sh[16];
+    __shared__ int shi[16];
+    constexpr int PER = 64;                 // up to 65536 ranks live in registers for the bisection
+    const bool in_regs = n <= PER * 1024;
+    int vals[PER];
     double c1 = 0, c5 = 0, c10 = 0, sum = 0, isum = 0;
     int mx = 0, mn = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = j * 1024 + threadIdx.x;
+        vals[j] = (in_regs && i < n) ? r[i] : 0x7fffffff;      // sentinel never counts as <= mid
+    }
     for (int i = threadIdx.x; i < n; i += 1024) {
         const int v = r[i];
         c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
@@ -193,21 +214,25 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     int lo = mn, hi = mx;
     while (lo < hi) {
         const int mid = lo + (hi - lo) / 2;
-        double c = 0;
-        for (int i = threadIdx.x; i < n; i += 1024) c += r[i] <= mid;
-        c = block_sum(c, sh);
+        int c = 0;
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) c += vals[j] <= mid;
+        } else {
+            for (int i = threadIdx.x; i < n; i += 1024) c += r[i] <= mid;
+        }
+        c = block_sum_int(c, shi);
         if (c >= k + 1) hi = mid; else lo = mid + 1;
     }
     double med = lo;
     if ((n & 1) == 0) {
         // sorted[k-1]: equals sorted[k] unless exactly k elements are smaller, then it is the largest of those
-        double cl = 0;
-        int below = 0;
+        int cl = 0, below = 0;
         for (int i = threadIdx.x; i < n; i += 1024) {
             const int v = r[i];
             if (v < lo) { cl += 1; below = max(below, v); }
         }
-        cl = block_sum(cl, sh);
+        cl = block_sum_int(cl, shi);
         below = block_max(below, sh);
         const double prev = (cl >= k) ? (double)below : (double)lo;
         med = 0.5 * (med + prev);
