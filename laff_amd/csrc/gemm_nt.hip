@@ -30,6 +30,8 @@
 namespace laff {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -147,6 +149,11 @@ __device__ __forceinline__ void glds_issue(const unsigned (&off)[IT], unsigned l
             : "v"(off[0]), "v"(off[1]), "s"(sbase), "s"(d0), "s"(d0 + stride)
             : "memory");
     }
+}
+
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long x) {     // make wave-uniformity provable
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // blockIdx -> linear tile id such that each XCD (block b runs on XCD b % 8) works on a contiguous chunk of tiles
@@ -335,27 +342,45 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
             offC[it] = (unsigned)min(c0 + row, a.nC - 1) * (unsigned)ldCb + (unsigned)swz(row, p & 7) * 16u;
         }
     }
-    auto stage = [&](int kt, int buf) {
-        const int seg = kt / kt_per_seg;
-        const long kb0 = (long)(kt - seg * kt_per_seg) * ROWB;
+    // Running scalar state of the operand stream (segment, K-step inside it, current base addresses): advanced by one
+    // K-step per stage_next() call, so the loop needs no division, no table lookup and no scalar memory load (scalar
+    // loads share lgkmcnt with the hand-counted LDS reads below and return out of order).
+    int st_seg = 0, st_kin = 0;
+    unsigned long long curR = (unsigned long long)((const char*)a.R + a.segR[0]);
+    unsigned long long curC = (unsigned long long)((const char*)a.C + a.segC[0]);
+    const unsigned long long nR1 = (unsigned long long)((const char*)a.R + a.segR[1]), nC1 = (unsigned long long)((const char*)a.C + a.segC[1]);
+    const unsigned long long nR2 = (unsigned long long)((const char*)a.R + a.segR[2]), nC2 = (unsigned long long)((const char*)a.C + a.segC[2]);
+    auto stage_next = [&](int buf) {             // stages K-steps in order: call k stages step k
+        const long kb0 = (long)st_kin * ROWB;
         char* s = smem + buf * CF::STAGEB;
         const unsigned sa = lds0 + (unsigned)buf * CF::STAGEB;
         if constexpr (STG == 2) {
             const unsigned wbase = (unsigned)(tid & ~63) * 16u;
-            glds_issue<CF::ITR>(offR, (unsigned long long)((const char*)a.R + a.segR[seg] + kb0), sa + wbase, THREADS * 16u);
-            glds_issue<CF::ITC>(offC, (unsigned long long)((const char*)a.C + a.segC[seg] + kb0), sa + CF::OPB_R + wbase,
-                                THREADS * 16u);
+            glds_issue<CF::ITR>(offR, uniform64(curR + (unsigned long long)kb0), sa + wbase, THREADS * 16u);
+            glds_issue<CF::ITC>(offC, uniform64(curC + (unsigned long long)kb0), sa + CF::OPB_R + wbase, THREADS * 16u);
         } else {
-            stage_operand<STG, CF::TR, THREADS>((const char*)a.R + a.segR[seg], r0, a.nR, ldRb, kb0, Kb, s, sa, tid);
-            stage_operand<STG, CF::TC, THREADS>((const char*)a.C + a.segC[seg], c0, a.nC, ldCb, kb0, Kb, s + CF::OPB_R,
-                                                sa + CF::OPB_R, tid);
+            stage_operand<STG, CF::TR, THREADS>((const char*)curR, r0, a.nR, ldRb, kb0, Kb, s, sa, tid);
+            stage_operand<STG, CF::TC, THREADS>((const char*)curC, c0, a.nC, ldCb, kb0, Kb, s + CF::OPB_R, sa + CF::OPB_R, tid);
+        }
+        if (++st_kin == kt_per_seg) {            // wave-uniform
+            st_kin = 0;
+            ++st_seg;
+            curR = st_seg == 1 ? nR1 : nR2;
+            curC = st_seg == 1 ? nC1 : nC2;
         }
     };
+
+    // per-lane LDS byte addresses of the fragment reads (stage 0): row base + swizzled 16-byte chunk of each sub-step
+    const unsigned laneR = lds0 + (unsigned)(wr * (WM * 32) + l31) * ROWB;
+    const unsigned laneC = lds0 + CF::OPB_R + (unsigned)(wc * (WN * 32) + l31) * ROWB;
+    unsigned xk[ROWB / 32];
+#pragma unroll
+    for (int ks = 0; ks < ROWB / 32; ++ks) xk[ks] = (unsigned)(((2 * ks + hh) ^ ((l31 >> 1) & 7)) * 16);
 
     // ring of 2 stages, ONE barrier per K-step:
     //   wait(stage kt landed) -> barrier -> issue stage kt+1 into the slot read in step kt-1 -> compute(kt)
     TRACE(1);
-    stage(0, 0);
+    stage_next(0);
     for (int kt = 0; kt < nkt; ++kt) {
         if constexpr (GLDS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -366,35 +391,83 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
         } else {
             __syncthreads();
         }
-        if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nkt) stage_next((kt + 1) & 1);
         const char* sR = smem + (kt & 1) * CF::STAGEB;
         const char* sC = sR + CF::OPB_R;
+        if constexpr (STG == 2) {
+            // Hand-pipelined LDS -> MFMA: the WM+WN ds_read_b128 of sub-step ks+1 are issued (inline asm, so hipcc cannot
+            // sink them next to their uses) BEFORE the MFMAs of sub-step ks; a counted lgkmcnt leaves exactly those reads
+            // in flight.  Left to itself hipcc keeps one fragment set and waits ~150 cycles per MFMA group
+            // (60-68 % matrix-pipe utilisation inside the K loop).
+            constexpr int NR = WM + WN;
+            const unsigned stg_off = (unsigned)(kt & 1) * CF::STAGEB;
+            u32x4 fc[2][WN], fr[2][WM];
+            auto issue = [&](int ks, int b) {
+                const unsigned ar = laneR + stg_off + xk[ks], ac = laneC + stg_off + xk[ks];
 #pragma unroll
-        for (int ks = 0; ks < ROWB / 32; ++ks) {
-            const int chunk = 2 * ks + hh;
-            uint4 fc[WN], fr[WM];
+                for (int t = 0; t < WN; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fc[b][t]) : "v"(ac), "n"(t * 32 * ROWB));
 #pragma unroll
-            for (int t = 0; t < WN; ++t) fc[t] = lds_frag(sC, wc * (WN * 32) + t * 32 + l31, chunk);
+                for (int t = 0; t < WM; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[b][t]) : "v"(ar), "n"(t * 32 * ROWB));
+            };
+            issue(0, 0);
 #pragma unroll
-            for (int t = 0; t < WM; ++t) fr[t] = lds_frag(sR, wr * (WM * 32) + t * 32 + l31, chunk);
-#pragma unroll
-            for (int tr = 0; tr < WM; ++tr)
-#pragma unroll
-                for (int tc = 0; tc < WN; ++tc) {
-                    if constexpr (MODE == GEMM_F32) {
-                        const float* pa = (const float*)&fc[tc];
-                        const float* pb = (const float*)&fr[tr];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[e], pb[e], acc[tr][tc], 0, 0, 0);
-                    } else if constexpr (MODE == GEMM_F16) {
-                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            __builtin_bit_cast(f16x8, fc[tc]), __builtin_bit_cast(f16x8, fr[tr]), acc[tr][tc], 0, 0, 0);
-                    } else {
-                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, fc[tc]), __builtin_bit_cast(bf16x8, fr[tr]), acc[tr][tc], 0, 0, 0);
-                    }
+            for (int ks = 0; ks < ROWB / 32; ++ks) {
+                const int b = ks & 1;
+                if (ks + 1 < ROWB / 32) {
+                    issue(ks + 1, b ^ 1);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tr = 0; tr < WM; ++tr)
+#pragma unroll
+                    for (int tc = 0; tc < WN; ++tc) {
+                        if constexpr (MODE == GEMM_F32) {
+                            const f32x4 pa = __builtin_bit_cast(f32x4, fc[b][tc]), pb = __builtin_bit_cast(f32x4, fr[b][tr]);
+                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.x, pb.x, acc[tr][tc], 0, 0, 0);
+                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.y, pb.y, acc[tr][tc], 0, 0, 0);
+                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.z, pb.z, acc[tr][tc], 0, 0, 0);
+                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.w, pb.w, acc[tr][tc], 0, 0, 0);
+                        } else if constexpr (MODE == GEMM_F16) {
+                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                __builtin_bit_cast(f16x8, fc[b][tc]), __builtin_bit_cast(f16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
+                        } else {
+                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, fc[b][tc]), __builtin_bit_cast(bf16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < ROWB / 32; ++ks) {
+                const int chunk = 2 * ks + hh;
+                uint4 fc[WN], fr[WM];
+#pragma unroll
+                for (int t = 0; t < WN; ++t) fc[t] = lds_frag(sC, wc * (WN * 32) + t * 32 + l31, chunk);
+#pragma unroll
+                for (int t = 0; t < WM; ++t) fr[t] = lds_frag(sR, wr * (WM * 32) + t * 32 + l31, chunk);
+#pragma unroll
+                for (int tr = 0; tr < WM; ++tr)
+#pragma unroll
+                    for (int tc = 0; tc < WN; ++tc) {
+                        if constexpr (MODE == GEMM_F32) {
+                            const float* pa = (const float*)&fc[tc];
+                            const float* pb = (const float*)&fr[tr];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[e], pb[e], acc[tr][tc], 0, 0, 0);
+                        } else if constexpr (MODE == GEMM_F16) {
+                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                __builtin_bit_cast(f16x8, fc[tc]), __builtin_bit_cast(f16x8, fr[tr]), acc[tr][tc], 0, 0, 0);
+                        } else {
+                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, fc[tc]), __builtin_bit_cast(bf16x8, fr[tr]), acc[tr][tc], 0, 0, 0);
+                        }
+                    }
+            }
         }
         if constexpr (!GLDS) __syncthreads();
     }
