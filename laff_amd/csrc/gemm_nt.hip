@@ -264,7 +264,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
                 const int gr = rbase + row;
                 float* o = a.out + (long)gr * a.ldo + gc;
                 if constexpr (FULL) {
-                    *(float4*)o = v;
+                    // streamed once, never re-read by this kernel: keep the score tile out of the L2 that holds the panels
+                    __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), (f32x4*)o);
                 } else if (gr < a.nR) {
                     const bool vec_ok = ((a.ldo & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0);
                     if (vec_ok && gc + 3 < a.nC) {
@@ -377,70 +378,93 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
 #pragma unroll
     for (int ks = 0; ks < ROWB / 32; ++ks) xk[ks] = (unsigned)(((2 * ks + hh) ^ ((l31 >> 1) & 7)) * 16);
 
-    // ring of 2 stages, ONE barrier per K-step:
-    //   wait(stage kt landed) -> barrier -> issue stage kt+1 into the slot read in step kt-1 -> compute(kt)
     TRACE(1);
-    stage_next(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        if constexpr (GLDS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt == 0) TRACE(2);
-            if (kt == 1) TRACE(3);
-        } else {
-            __syncthreads();
-        }
-        if (kt + 1 < nkt) stage_next((kt + 1) & 1);
-        const char* sR = smem + (kt & 1) * CF::STAGEB;
-        const char* sC = sR + CF::OPB_R;
-        if constexpr (STG == 2) {
-            // Hand-pipelined LDS -> MFMA: the WM+WN ds_read_b128 of sub-step ks+1 are issued (inline asm, so hipcc cannot
-            // sink them next to their uses) BEFORE the MFMAs of sub-step ks; a counted lgkmcnt leaves exactly those reads
-            // in flight.  Left to itself hipcc keeps one fragment set and waits ~150 cycles per MFMA group
-            // (60-68 % matrix-pipe utilisation inside the K loop).
-            constexpr int NR = WM + WN;
+    if constexpr (STG == 2) {
+        // ---- software-pipelined K loop (fast staging) ---------------------------------------------------------------
+        // ring of 2 LDS stages, ONE barrier per K-step, placed in front of the LAST sub-step's MFMAs:
+        //   sub-steps 0..2 : issue the ds_reads of the next sub-step, counted lgkmcnt, 2*WM*WN... MFMAs on the current one
+        //   sub-step 3     : lgkmcnt(0) (own fragments) + vmcnt(0) (stage kt+1 landed) -> s_barrier (every wave has
+        //                    finished READING stage kt and every wave's part of stage kt+1 is visible) -> LDS-DMA of
+        //                    stage kt+2 into the slot just released -> ds_reads of sub-step 0 of K-step kt+1 -> MFMAs
+        // so LDS latency, DMA issue and barrier skew all sit under a group of MFMAs instead of in front of one.
+        // The reads are inline asm (hipcc would sink them next to their uses and keep a single fragment set).
+        constexpr int NR = WM + WN, NSUB = ROWB / 32;
+        u32x4 fc[2][WN], fr[2][WM];
+        auto issue = [&](int kt, int ks, int b) {
             const unsigned stg_off = (unsigned)(kt & 1) * CF::STAGEB;
-            u32x4 fc[2][WN], fr[2][WM];
-            auto issue = [&](int ks, int b) {
-                const unsigned ar = laneR + stg_off + xk[ks], ac = laneC + stg_off + xk[ks];
+            const unsigned ar = laneR + stg_off + xk[ks], ac = laneC + stg_off + xk[ks];
 #pragma unroll
-                for (int t = 0; t < WN; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fc[b][t]) : "v"(ac), "n"(t * 32 * ROWB));
+            for (int t = 0; t < WN; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fc[b][t]) : "v"(ac), "n"(t * 32 * ROWB));
 #pragma unroll
-                for (int t = 0; t < WM; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[b][t]) : "v"(ar), "n"(t * 32 * ROWB));
-            };
-            issue(0, 0);
+            for (int t = 0; t < WM; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[b][t]) : "v"(ar), "n"(t * 32 * ROWB));
+        };
+        auto mfmas = [&](int b) {
 #pragma unroll
-            for (int ks = 0; ks < ROWB / 32; ++ks) {
-                const int b = ks & 1;
-                if (ks + 1 < ROWB / 32) {
-                    issue(ks + 1, b ^ 1);
-                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int tr = 0; tr < WM; ++tr)
 #pragma unroll
-                for (int tr = 0; tr < WM; ++tr)
-#pragma unroll
-                    for (int tc = 0; tc < WN; ++tc) {
-                        if constexpr (MODE == GEMM_F32) {
-                            const f32x4 pa = __builtin_bit_cast(f32x4, fc[b][tc]), pb = __builtin_bit_cast(f32x4, fr[b][tr]);
-                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.x, pb.x, acc[tr][tc], 0, 0, 0);
-                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.y, pb.y, acc[tr][tc], 0, 0, 0);
-                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.z, pb.z, acc[tr][tc], 0, 0, 0);
-                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.w, pb.w, acc[tr][tc], 0, 0, 0);
-                        } else if constexpr (MODE == GEMM_F16) {
-                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                __builtin_bit_cast(f16x8, fc[b][tc]), __builtin_bit_cast(f16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
-                        } else {
-                            acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, fc[b][tc]), __builtin_bit_cast(bf16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
-                        }
+                for (int tc = 0; tc < WN; ++tc) {
+                    if constexpr (MODE == GEMM_F32) {
+                        const f32x4 pa = __builtin_bit_cast(f32x4, fc[b][tc]), pb = __builtin_bit_cast(f32x4, fr[b][tr]);
+                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.x, pb.x, acc[tr][tc], 0, 0, 0);
+                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.y, pb.y, acc[tr][tc], 0, 0, 0);
+                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.z, pb.z, acc[tr][tc], 0, 0, 0);
+                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.w, pb.w, acc[tr][tc], 0, 0, 0);
+                    } else if constexpr (MODE == GEMM_F16) {
+                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, fc[b][tc]), __builtin_bit_cast(f16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
+                    } else {
+                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, fc[b][tc]), __builtin_bit_cast(bf16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
                     }
+                }
+        };
+        static_assert(NSUB % 2 == 0, "fragment buffer parity must repeat every K-step");
+        // prologue: stage 0 landed and visible, stage 1 in flight, fragments of (K-step 0, sub-step 0) in flight
+        stage_next(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TRACE(2);
+        if (nkt > 1) stage_next(1);
+        issue(0, 0, 0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            if (kt == 1) TRACE(3);
+#pragma unroll
+            for (int ks = 0; ks < NSUB - 1; ++ks) {
+                issue(kt, ks + 1, (ks + 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(ks & 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
+            // last sub-step: its fragments are the only LDS reads outstanding
+            if (kt + 1 < nkt) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 2 < nkt) stage_next(kt & 1);                // slot of stage kt is free now
+                issue(kt + 1, 0, 0);
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas((NSUB - 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // ---- generic staging paths: compiler-scheduled loop, one barrier pair per K-step ------------------------------
+        stage_next(0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            if constexpr (GLDS) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            } else {
+                __syncthreads();
+            }
+            if (kt + 1 < nkt) stage_next((kt + 1) & 1);
+            const char* sR = smem + (kt & 1) * CF::STAGEB;
+            const char* sC = sR + CF::OPB_R;
 #pragma unroll
             for (int ks = 0; ks < ROWB / 32; ++ks) {
                 const int chunk = 2 * ks + hh;
@@ -468,8 +492,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
                         }
                     }
             }
+            if constexpr (!GLDS) __syncthreads();
         }
-        if constexpr (!GLDS) __syncthreads();
     }
 
     TRACE(4);
