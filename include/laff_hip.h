@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 2
+#define LAFF_ABI_VERSION 3
 
 enum {
     LAFF_OK = 0,
@@ -94,6 +94,9 @@ int laff_fc_act_bn_grouped(laff_ctx* ctx, const laff_fc_problem* problems /*host
  * 3 MFMA passes at the 2.5 PF fp16 rate instead of one at the 157 TF fp32 rate. */
 int laff_split_rows_bytes(int N, int K, size_t* out);            /* bytes of the [2][N][Kp] fp16 operand, Kp = ceil(K/64)*64 */
 int laff_split_rows(laff_ctx* ctx, const float* X, int N, int K, int ldx, void* out_hi_lo, float* rscale /*[N]*/);
+/* up to 8 matrices in one launch (host arrays of `count` entries) */
+int laff_split_rows_grouped(laff_ctx* ctx, int count, const float* const* X, const int* N, const int* K, const int* ldx,
+                            void* const* out_hi_lo, float* const* rscale);
 typedef struct {
     const void* Xs; const float* x_rscale; int N, Dk;          /* laff_split_rows(X[N,Dk]) */
     const void* Ws; const float* w_rscale;                      /* laff_split_rows(W[D,Dk]) */
@@ -122,6 +125,12 @@ typedef struct {
  * L <= 8, d % 4 == 0.  With NO_SPLIT_HEAD every head reads columns [0,d) (d = D). */
 int laff_fuse(laff_ctx* ctx, const laff_plane* planes /*host array of L*/, int L, int N, int H, int d,
               const float* w, const float* b, const float* gw, unsigned flags, float* E, float* attn_w);
+
+/* laff_fuse that ALSO emits the single-plane 16-bit similarity operand E16[N, H*d] = E * prescale (LAFF_PREC_FP16 or
+ * LAFF_PREC_BF16), saving the separate laff_pack_rows pass.  E is already unit-norm per (n,h) to fp32 rounding, so the
+ * re-normalisation loss.cosine_sim applies (loss.py:33) is a no-op at 16-bit precision. */
+int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
+                     const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale);
 
 /* ---- a7: per-video frame attention of VisMutiTransformNetPlusFrameFeat (model/model.py:2163-2173) --------
  * V[B,d] = Attention_1 over the Fmax frames of each video; frames[B,Fmax,d] zero padded.

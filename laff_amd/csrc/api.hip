@@ -183,6 +183,23 @@ int laff_split_rows(laff_ctx* ctx, const float* X, int N, int K, int ldx, void* 
     return LAFF_OK;
 }
 
+int laff_split_rows_grouped(laff_ctx* ctx, int count, const float* const* X, const int* N, const int* K, const int* ldx,
+                            void* const* out, float* const* rscale) {
+    CHECK_CTX(ctx);
+    if (count < 0 || (count && (!X || !N || !K || !ldx || !out || !rscale))) return fail(LAFF_E_ARG, "laff_split_rows_grouped: bad argument list");
+    DeviceGuard g(ctx->device);
+    for (int i0 = 0; i0 < count; i0 += 8) {
+        const int c = count - i0 < 8 ? count - i0 : 8;
+        for (int i = i0; i < i0 + c; ++i) {
+            if (!X[i] || !out[i] || !rscale[i]) return fail(LAFF_E_ARG, "laff_split_rows_grouped: matrix %d has a null pointer", i);
+            if (N[i] < 0 || K[i] < 1 || ldx[i] < K[i]) return fail(LAFF_E_SHAPE, "laff_split_rows_grouped: matrix %d bad shape", i);
+            if (!aligned16(out[i])) return fail(LAFF_E_ALIGN, "laff_split_rows_grouped: out %d must be 16-byte aligned", i);
+        }
+        HIP_TRY(laff::launch_split_rows_grouped(c, X + i0, N + i0, K + i0, ldx + i0, out + i0, rscale + i0, ctx->stream));
+    }
+    return LAFF_OK;
+}
+
 int laff_fc_act_bn_split_grouped(laff_ctx* ctx, const laff_fc_split_problem* problems, int count) {
     CHECK_CTX(ctx);
     if (!problems || count < 0) return fail(LAFF_E_ARG, "laff_fc_act_bn_split_grouped: bad problem list");
@@ -219,9 +236,21 @@ int laff_fc_act_bn_split_grouped(laff_ctx* ctx, const laff_fc_split_problem* pro
     return LAFF_OK;
 }
 
+int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
+                     const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale);
+
 int laff_fuse(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
               const float* gw, unsigned flags, float* E, float* attn_w) {
+    return laff_fuse_packed(ctx, planes, L, N, H, d, w, b, gw, flags, E, attn_w, nullptr, LAFF_PREC_FP16, 1.0f);
+}
+
+int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
+                     const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale) {
     CHECK_CTX(ctx);
+    if (E16 && precision != LAFF_PREC_FP16 && precision != LAFF_PREC_BF16)
+        return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed: E16 is a single-plane operand (FP16 or BF16), got precision %d", precision);
+    if (E16 && !aligned16(E16)) return fail(LAFF_E_ALIGN, "laff_fuse_packed: E16 must be 16-byte aligned");
+    if (E16 && (flags & LAFF_ATT_JUST_AVERAGE)) return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed: JUST_AVERAGE output is not unit-norm");
     if (!planes || !E) return fail(LAFF_E_ARG, "laff_fuse: null planes/E");
     if (L < 1 || L > laff::MAX_L) return fail(LAFF_E_SHAPE, "laff_fuse: L=%d outside [1,%d]", L, laff::MAX_L);
     if (N < 0 || H < 1 || d < 4 || (d & 3)) return fail(LAFF_E_SHAPE, "laff_fuse: need N>=0, H>=1, d%%4==0 (N=%d H=%d d=%d)", N, H, d);
@@ -245,6 +274,7 @@ int laff_fuse(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int 
     if (N == 0) return LAFF_OK;
     a.L = L; a.N = N; a.H = H; a.d = d; a.head_stride = nosplit ? 0 : d;
     a.w = w; a.b = b; a.gw = gw; a.flags = flags; a.E = E; a.attn_w = attn_w;
+    a.E16 = E16; a.e16_bf16 = precision == LAFF_PREC_BF16; a.e16_scale = prescale;
     DeviceGuard g(ctx->device);
     HIP_TRY(laff::launch_fuse(a, ctx->stream));
     return LAFF_OK;

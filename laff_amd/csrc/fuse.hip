@@ -49,6 +49,18 @@ __device__ __forceinline__ float4 load_plane(const FuseArgs& a, int l, long n, i
     return v;
 }
 
+__device__ __forceinline__ void store16x4(void* base, long idx, float4 v, float scale, int bf16) {
+    if (bf16) {
+        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+        b4 o = {(__bf16)(v.x * scale), (__bf16)(v.y * scale), (__bf16)(v.z * scale), (__bf16)(v.w * scale)};
+        *(b4*)((__bf16*)base + idx) = o;
+    } else {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 o = {(_Float16)(v.x * scale), (_Float16)(v.y * scale), (_Float16)(v.z * scale), (_Float16)(v.w * scale)};
+        *(h4*)((_Float16*)base + idx) = o;
+    }
+}
+
 // softmax over L logits held identically by every lane
 template <int L>
 __device__ __forceinline__ void softmax_L(float (&lg)[L]) {
@@ -145,7 +157,10 @@ __global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int col = j * 256 + lane * 4;
-        if (col < d) *(float4*)(a.E + item * d + col) = g[j];
+        if (col < d) {
+            *(float4*)(a.E + item * d + col) = g[j];
+            if (a.E16) store16x4(a.E16, item * d + col, g[j], a.e16_scale, a.e16_bf16);
+        }
     }
 }
 
@@ -221,7 +236,9 @@ __global__ __launch_bounds__(256) void fuse_stream_kernel(FuseArgs a) {
     // each lane rescales exactly the elements it wrote itself
     for (int col = lane * 4; col < d; col += 256) {
         float4* e = (float4*)(a.E + item * d + col);
-        *e = scl4(*e, inv);
+        const float4 v = scl4(*e, inv);
+        *e = v;
+        if (a.E16) store16x4(a.E16, item * d + col, v, a.e16_scale, a.e16_bf16);
     }
 }
 
@@ -453,54 +470,112 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
 // magnitude, lo stays normal down to 2^-34 of the row maximum), hi = fp16(x*s), lo = fp16(x*s - hi).  fp16 x fp16
 // products are exact in fp32, so hi*hi' + hi*lo' + lo*hi' reproduces the fp32 product to ~2^-22 relative.
 // out: [2][N][Kp] fp16 (hi plane, lo plane), columns >= K zero filled; rscale[n] = 1/s (a power of two: exact).
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, int N, int K, int ldx, int Kp,
-                                                         _Float16* __restrict__ out, float* __restrict__ rscale) {
+struct SplitArgs {              // up to 8 matrices in one launch; block -> (matrix, group of 4 rows) by scalar search
+    int count;
+    int block_start[9];
+    const float* X[8];
+    int N[8], K[8], ldx[8], Kp[8];
+    _Float16* out[8];
+    float* rscale[8];
+};
+
+// NCH > 0: the row (K <= 256*NCH, 16-byte aligned) stays in registers between the max pass and the convert pass;
+// NCH == 0: generic (any K / alignment), second pass re-reads the row through L2.
+template <int NCH>
+__global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs g) {
     const int lane = threadIdx.x & 63;
-    const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int p = 0;
+    while (p + 1 < g.count && (int)blockIdx.x >= g.block_start[p + 1]) ++p;
+    const long n = (long)((int)blockIdx.x - g.block_start[p]) * 4 + (threadIdx.x >> 6);
+    const int N = g.N[p], K = g.K[p], ldx = g.ldx[p], Kp = g.Kp[p];
     if (n >= N) return;
-    const float* src = X + n * ldx;
-    const bool vec = !(K & 3) && !(ldx & 3) && !((uintptr_t)X & 15);
+    const float* src = g.X[p] + n * ldx;
+    _Float16* hi = g.out[p] + n * Kp;
+    _Float16* lo = g.out[p] + (long)N * Kp + n * Kp;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     float m = 0.f;
-    if (vec) {
-        for (int c = lane * 4; c < K; c += 256) {
-            const float4 v = *(const float4*)(src + c);
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if constexpr (NCH > 0) {
+        float4 v[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            v[j] = c < K ? *(const float4*)(src + c) : make_float4(0, 0, 0, 0);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+        }
+        m = wave_max(m);
+        int e = 0;
+        if (m > 0.f && m < INFINITY) e = ilogbf(m);
+        const float s = ldexpf(1.0f, 9 - e);
+        if (lane == 0) g.rscale[p][n] = ldexpf(1.0f, e - 9);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < Kp) {
+                const float t[4] = {v[j].x * s, v[j].y * s, v[j].z * s, v[j].w * s};
+                h4 h, l;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h[q] = (_Float16)t[q];
+                    l[q] = (_Float16)(t[q] - (float)h[q]);
+                }
+                *(h4*)(hi + c) = h;
+                *(h4*)(lo + c) = l;
+            }
         }
     } else {
         for (int c = lane; c < K; c += 64) m = fmaxf(m, fabsf(src[c]));
-    }
-    m = wave_max(m);
-    int e = 0;
-    if (m > 0.f && m < INFINITY) e = ilogbf(m);
-    const float s = ldexpf(1.0f, 9 - e);
-    if (lane == 0) rscale[n] = ldexpf(1.0f, e - 9);
-    _Float16* hi = out + n * Kp;
-    _Float16* lo = out + (long)N * Kp + n * Kp;
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    for (int c = lane * 4; c < Kp; c += 256) {       // Kp % 64 == 0, rows of the packed operand are 128-byte aligned
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (vec && c + 3 < K) {
-            *(float4*)v = *(const float4*)(src + c);
-        } else {
+        m = wave_max(m);
+        int e = 0;
+        if (m > 0.f && m < INFINITY) e = ilogbf(m);
+        const float s = ldexpf(1.0f, 9 - e);
+        if (lane == 0) g.rscale[p][n] = ldexpf(1.0f, e - 9);
+        for (int c = lane * 4; c < Kp; c += 256) {       // Kp % 64 == 0, rows of the packed operand are 128-byte aligned
+            h4 h, l;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (c + j < K) v[j] = src[c + j];
+            for (int q = 0; q < 4; ++q) {
+                const float t = (c + q < K ? src[c + q] : 0.f) * s;
+                h[q] = (_Float16)t;
+                l[q] = (_Float16)(t - (float)h[q]);
+            }
+            *(h4*)(hi + c) = h;
+            *(h4*)(lo + c) = l;
         }
-        h4 h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float t = v[j] * s;
-            h[j] = (_Float16)t;
-            l[j] = (_Float16)(t - (float)h[j]);
-        }
-        *(h4*)(hi + c) = h;
-        *(h4*)(lo + c) = l;
     }
 }
 
-hipError_t launch_split_rows(const float* X, int N, int K, int ldx, int Kp, void* out, float* rscale, hipStream_t st) {
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, X, N, K, ldx, Kp, (_Float16*)out, rscale);
+hipError_t launch_split_rows_grouped(int count, const float* const* X, const int* N, const int* K, const int* ldx, void* const* out,
+                                     float* const* rscale, hipStream_t st) {
+    if (count < 1 || count > 8) return hipErrorInvalidValue;
+    SplitArgs g{};
+    g.count = count;
+    int nb = 0, kmax = 0;
+    bool vec = true;
+    for (int i = 0; i < count; ++i) {
+        g.block_start[i] = nb;
+        nb += (N[i] + 3) / 4;
+        g.X[i] = X[i]; g.N[i] = N[i]; g.K[i] = K[i]; g.ldx[i] = ldx[i]; g.Kp[i] = (K[i] + 63) / 64 * 64;
+        g.out[i] = (_Float16*)out[i]; g.rscale[i] = rscale[i];
+        kmax = K[i] > kmax ? K[i] : kmax;
+        vec = vec && !(K[i] & 3) && !(ldx[i] & 3) && !((uintptr_t)X[i] & 15);
+    }
+    g.block_start[count] = nb;
+    if (nb == 0) return hipSuccess;
+    const dim3 grid((unsigned)nb), block(256);
+    if (vec && kmax <= 256) hipLaunchKernelGGL((split_rows_kernel<1>), grid, block, 0, st, g);
+    else if (vec && kmax <= 512) hipLaunchKernelGGL((split_rows_kernel<2>), grid, block, 0, st, g);
+    else if (vec && kmax <= 1024) hipLaunchKernelGGL((split_rows_kernel<4>), grid, block, 0, st, g);
+    else if (vec && kmax <= 2048) hipLaunchKernelGGL((split_rows_kernel<8>), grid, block, 0, st, g);
+    else if (vec && kmax <= 4096) hipLaunchKernelGGL((split_rows_kernel<16>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((split_rows_kernel<0>), grid, block, 0, st, g);
     return hipGetLastError();
+}
+
+hipError_t launch_split_rows(const float* X, int N, int K, int ldx, int Kp, void* out, float* rscale, hipStream_t st) {
+    (void)Kp;
+    const float* xs[1] = {X};
+    void* os[1] = {out};
+    float* rs[1] = {rscale};
+    return launch_split_rows_grouped(1, xs, &N, &K, &ldx, os, rs, st);
 }
 
 hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,

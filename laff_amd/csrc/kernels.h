@@ -62,6 +62,9 @@ struct FuseArgs {
     unsigned flags;
     float* E;             // [N, H, d]
     float* attn_w;        // [N, H, L] or null
+    void* E16;            // optional [N, H*d] 16-bit GEMM operand (E * e16_scale), fp16 or bf16
+    int e16_bf16;
+    float e16_scale;
 };
 hipError_t launch_fuse(const FuseArgs& a, hipStream_t st);
 
@@ -77,6 +80,8 @@ struct FrameArgs {
 };
 hipError_t launch_frame_fuse(const FrameArgs& a, hipStream_t st);
 
+hipError_t launch_split_rows_grouped(int count, const float* const* X, const int* N, const int* K, const int* ldx, void* const* out,
+                                     float* const* rscale, hipStream_t st);
 hipError_t launch_split_rows(const float* X, int N, int K, int ldx, int Kp, void* out, float* rscale, hipStream_t st);
 hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,
                             int precision, void* out, hipStream_t st);

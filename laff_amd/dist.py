@@ -36,21 +36,55 @@ class HipBackend:
     def embed_both(self, vis_feats, txt_feats):
         """Single-rank shortcut: both towers' FC projections in one grouped launch."""
         from .retrieval import embed
-        return embed(self.model, vis_feats, txt_feats)
+        self._emit_packed(True)
+        try:
+            return embed(self.model, vis_feats, txt_feats)
+        finally:
+            self._emit_packed(False)
+
+    def txt_layer(self):
+        return self.model.txt_net.attention_layer
+
+    def vis_layer(self):
+        net = self.model.vis_net
+        return getattr(net, 'attention_layer', None) or getattr(net, 'vis_attention_layer', None)
 
     def embed_text(self, txt_feats):
         cap = dict(txt_feats)
         cap.setdefault('caption', None)
-        return self.model.txt_net(cap)
+        self._emit_packed(True)
+        try:
+            return self.model.txt_net(cap)
+        finally:
+            self._emit_packed(False)
 
     def embed_video(self, vis_feats):
         vis = dict(vis_feats)
         frame_dict = {}
         if 'mask_tensor' in vis:
             frame_dict, vis = vis, {}
-        return self.model.vis_net(vis, vis_frame_feat_dict_input=frame_dict)
+        self._emit_packed(True)
+        try:
+            return self.model.vis_net(vis, vis_frame_feat_dict_input=frame_dict)
+        finally:
+            self._emit_packed(False)
 
-    def pack(self, E):
+    def _attention_layers(self):
+        return [getattr(net, name) for net in (self.model.vis_net, self.model.txt_net)
+                for name in ('attention_layer', 'vis_attention_layer') if hasattr(net, name)]
+
+    def _emit_packed(self, on):
+        fused = self.precision in ('fp16', 'bf16')
+        for layer in self._attention_layers():
+            layer.emit_packed = self.precision if (on and fused and hasattr(layer, 'fuse_planes') and
+                                                   type(layer).__name__ != 'JustAverage') else None
+
+    def pack(self, E, layer=None):
+        """GEMM operand of an embedding matrix: taken from the fuse launch when it emitted one, else a pack_rows pass."""
+        p = getattr(layer, 'last_packed', None) if layer is not None else None
+        if p is not None and p.N == E.shape[0]:
+            layer.last_packed = None
+            return p
         return ops.pack_rows(E, True, 1e-13, self.precision)
 
     def operand_from_gathered(self, bufs, rows, K, like):
@@ -93,7 +127,7 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
         else:
             txt_emb = compute.embed_text(txt_feats_local)
             mark('txt_tower')
-        T_local = compute.pack(txt_emb)
+        T_local = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
         mark('pack')
         work = None
         if world > 1:
@@ -114,7 +148,7 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
         if vis_emb is None:
             vis_emb = compute.embed_video(vis_feats_local)
             mark('vis_tower')
-        V_local = compute.pack(vis_emb)
+        V_local = compute.pack(vis_emb, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack(vis_emb)
         mark('pack')
         if world > 1:
             work.wait()

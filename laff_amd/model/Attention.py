@@ -66,7 +66,10 @@ class Attention_1(nn.Module):
             raise NotImplementedError('laff_amd implements the inference path only; call .eval()')
         w, b, gw = self._params()
         flags = ops.attention_flags(self.with_ave, self.mul)
-        E, aw = ops.fuse(planes, 1, self.embed_dim, w, b, gw, flags, return_weights=True)
+        packed = getattr(self, 'emit_packed', None)       # 'fp16' | 'bf16': also emit the GEMM operand (last_packed)
+        res = ops.fuse(planes, 1, self.embed_dim, w, b, gw, flags, return_weights=True, packed_precision=packed)
+        E, aw = res[0], res[1]
+        self.last_packed = res[2] if packed else None
         aw = aw[:, 0, :]
         if self.with_ave:   # what the reference stashes in that case (Attention.py:97)
             aw = aw + gw / aw.shape[1]
@@ -122,7 +125,10 @@ class Multi_head_MyApply_Attention(nn.Module):
             raise NotImplementedError('laff_amd implements the inference path only; call .eval()')
         w, b, gw = self._params()
         flags = ops.attention_flags(self.with_ave, self.mul, self.l2norm_each_head, self.split_head)
-        E, aw = ops.fuse(planes, self.multi_heads, self.head_dim, w, b, gw, flags, return_weights=True)
+        packed = getattr(self, 'emit_packed', None)       # 'fp16' | 'bf16': also emit the GEMM operand (last_packed)
+        res = ops.fuse(planes, self.multi_heads, self.head_dim, w, b, gw, flags, return_weights=True, packed_precision=packed)
+        E, aw = res[0], res[1]
+        self.last_packed = res[2] if packed else None
         for h in range(self.multi_heads):
             a = aw[:, h, :]
             self.attention_layer[h].weights = a + gw[h] / a.shape[1] if self.with_ave else a

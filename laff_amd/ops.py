@@ -145,6 +145,26 @@ def split_rows(x):
     return SplitOperand(buf, rscale, N, K)
 
 
+def split_rows_grouped(xs):
+    """split_rows for several matrices in one launch."""
+    if not xs:
+        return []
+    n = len(xs)
+    lib, h = _context(xs[0].device)
+    X, N, K, LD, O, R = (C.c_void_p * n)(), (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    outs = []
+    for i, x in enumerate(xs):
+        x, ldx = _rows(x, 'x')
+        nbytes = C.c_size_t()
+        check(lib.laff_split_rows_bytes(x.shape[0], x.shape[1], C.byref(nbytes)))
+        buf = torch.empty((max(nbytes.value, 16),), device=x.device, dtype=torch.uint8)
+        rscale = torch.empty((max(x.shape[0], 1),), device=x.device, dtype=torch.float32)
+        X[i], N[i], K[i], LD[i], O[i], R[i] = x.data_ptr(), x.shape[0], x.shape[1], ldx, buf.data_ptr(), rscale.data_ptr()
+        outs.append(SplitOperand(buf, rscale, x.shape[0], x.shape[1]))
+    _call('split_rows', lib.laff_split_rows_grouped, h, n, X, N, K, LD, O, R)
+    return outs
+
+
 def fc_act_bn_split_grouped(problems):
     """fc_act_bn_grouped on the fp16 matrix pipe with fp32-class accuracy.  problems: dicts with x (fp32 tensor or
     SplitOperand), weight_split (SplitOperand of W), optional bias / bn_scale / bn_shift / activation / out."""
@@ -153,8 +173,10 @@ def fc_act_bn_split_grouped(problems):
     arr = (FcSplitProblem * len(problems))()
     outs, keep = [], []
     dev = problems[0]['weight_split'].buf.device
+    todo = [i for i, q in enumerate(problems) if not isinstance(q['x'], SplitOperand)]
+    split = dict(zip(todo, split_rows_grouped([problems[i]['x'] for i in todo])))      # all inputs in ONE launch
     for i, q in enumerate(problems):
-        xs = q['x'] if isinstance(q['x'], SplitOperand) else split_rows(q['x'])
+        xs = split.get(i, q['x'])
         ws = q['weight_split']
         if xs.K != ws.K:
             raise ValueError('problem %d: x has %d columns, weight %d' % (i, xs.K, ws.K))
@@ -181,8 +203,9 @@ def fc_act_bn_split_grouped(problems):
     return outs
 
 
-def fuse(planes, H, d, w, b, gw, flags, return_weights=False):
-    """planes: list of (src[N, ld-view], tile, scale, shift).  Returns E (N, H, d) [and softmax weights (N, H, L)]."""
+def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=None):
+    """planes: list of (src[N, ld-view], tile, scale, shift).  Returns E (N, H, d) [and softmax weights (N, H, L)].
+    packed_precision ('fp16' | 'bf16'): also emit the similarity operand in the same launch; returned last."""
     L = len(planes)
     arr = (Plane * L)()
     N = planes[0][0].shape[0]
@@ -207,8 +230,19 @@ def fuse(planes, H, d, w, b, gw, flags, return_weights=False):
         if t is not None:
             _dev(t, nm)
     lib, h = _context(dev)
-    _call('fuse', lib.laff_fuse, h, arr, L, N, H, d, _ptr(w), _ptr(b), _ptr(gw), flags, _ptr(E), _ptr(aw))
-    return (E, aw) if return_weights else E
+    packed = None
+    if packed_precision is not None:
+        prescale = default_prescale(packed_precision)
+        buf = torch.empty((max(N * H * d * 2, 16),), device=dev, dtype=torch.uint8)
+        _call('fuse', lib.laff_fuse_packed, h, arr, L, N, H, d, _ptr(w), _ptr(b), _ptr(gw), flags, _ptr(E), _ptr(aw), _ptr(buf),
+              PREC[packed_precision], prescale)
+        packed = Packed(buf, N, H * d, packed_precision, prescale)
+    else:
+        _call('fuse', lib.laff_fuse, h, arr, L, N, H, d, _ptr(w), _ptr(b), _ptr(gw), flags, _ptr(E), _ptr(aw))
+    out = (E, aw) if return_weights else (E,)
+    if packed_precision is not None:
+        out = out + (packed,)
+    return out if len(out) > 1 else out[0]
 
 
 def frame_fuse(frames, lens, w, b, gw, flags):

@@ -347,3 +347,25 @@ def test_fc_split_fp16x3_vs_fp64(N, Dk, D):
         assert float(np.max(np.abs(y.cpu().numpy() - ref) / scale)) <= 2e-5
         y32 = ops.fc_act_bn(dev(x), dev(W), dev(b), dev(sc), dev(sh), act)
         assert float(np.max(np.abs((y - y32).cpu().numpy()) / scale)) <= 2e-5
+
+
+def test_fuse_emits_the_packed_operand():
+    """laff_fuse_packed: the 16-bit similarity operand written by the fuse launch equals laff_pack_rows of its fp32
+    output up to one fp16 ulp (E is unit-norm already, so the re-normalisation is a no-op at that precision)."""
+    from laff_amd import ops
+    g = rnd(81)
+    N, H, d, L = 50, 8, 512, 4
+    planes = [(dev(np.tanh(g.normal(0, 1, (N, H * d))).astype(np.float32)), False, None, None) for _ in range(L)]
+    w = dev((g.uniform(-1, 1, (H, d)) / np.sqrt(d)).astype(np.float32))
+    b = dev(g.normal(0, 0.3, H).astype(np.float32))
+    for prec, dt in (('fp16', torch.float16), ('bf16', torch.bfloat16)):
+        E, P = ops.fuse(planes, H, d, w, b, None, 0, packed_precision=prec)
+        Q = ops.pack_rows(E, True, 1e-13, prec)
+        a = P.buf[:N * H * d * 2].view(dt).float()
+        c = Q.buf[:N * H * d * 2].view(dt).float()
+        assert P.prescale == Q.prescale and P.K == Q.K == H * d
+        ulp = (2.0 ** -10 if prec == 'fp16' else 2.0 ** -7)
+        assert float(((a - c).abs() / (c.abs() + 1e-3)).max()) <= ulp
+        S1 = ops.sim_gemm(P, P, heads=H)
+        S2 = ops.sim_gemm(Q, Q, heads=H)
+        assert maxdiff(S1, S2) <= (1e-4 if prec == 'fp16' else 2e-3)
