@@ -136,3 +136,25 @@ def test_c5_laff_ml_100k_x_30k_bf16():
     assert float((strict - fast).abs().float().max()) <= max(3.0, 0.02 * float(strict.max()))
     r = res.ranks.cpu().numpy().astype(np.float64)
     assert abs(res.metrics[0] - 100.0 * np.mean(r <= 1)) < 1e-9
+
+
+def test_c4_video_to_text_positions():
+    """V2T direction at 40k x 10k (4 captions per video): device counts vs numpy on a sample of videos, and the 7 metrics
+    against evaluation.eval arithmetic from those positions."""
+    from laff_amd import predictor
+    res, gt = _c4()
+    S = res.S
+    owner = gt.cpu().numpy()
+    pos, order, off = predictor.v2t_positions(S, owner)
+    cols = np.arange(0, 10000, 397)
+    Sc = S[:, torch.as_tensor(cols, device=DEV)].cpu().numpy()
+    for j, v in enumerate(cols):
+        texts = np.where(owner == v)[0]
+        col = Sc[:, j]
+        exp = np.array([1 + np.sum(col > col[t]) for t in texts])
+        assert np.array_equal(pos[texts], exp)
+    m = predictor.v2t_metrics(S, owner)
+    first = np.array([pos[order[off[v]:off[v + 1]]].min() for v in range(10000)], dtype=np.float64)
+    assert abs(m[0] - 100.0 * np.mean(first <= 1)) < 1e-9 and m[3] == np.floor(np.median(first))
+    t2v = predictor.t2v_metrics(S, owner)
+    np.testing.assert_allclose(t2v, res.metrics, rtol=1e-13)
