@@ -283,6 +283,17 @@ def main():
             roof = {'kernel': 'laff_' + dom, 'bound': pk['bound'], 'achieved': pk['achieved'], 'peak': pk['peak'], 'unit': pk['unit'],
                     'frac': pk['frac'], 'traffic': None, 'launches_per_step': pk['launches_per_step'],
                     'avg_launch_ms': round(pk['ms_per_step'] / max(1, pk['launches_per_step']), 5)}
+        # measured HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command, committed under profiles/
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))
+            if (tj.get('workload') == args.workload and tj.get('precision') == args.precision and
+                    tj.get('fc_precision') == args.fc_precision and dom in tj['kernels'] and world == 1):
+                k = tj['kernels'][dom]
+                roof['traffic'] = round((k['fetch_corrected_MB'] + k['write_MB']) * 1e6)
+                roof['traffic_note'] = ('bytes per launch: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), rocprofv3 --pmc passes '
+                                        'of this command, profiles/r1_bench_pmc_*.txt; algorithmic %.0f MB' % k.get('algorithmic_MB', 0))
+        except Exception:  # noqa: BLE001
+            pass
         m = res['metrics']
         agreement = None
         if world == 1 and not args.no_cpu_baseline and not args.precision.endswith('x3') and args.precision != 'fp32':
