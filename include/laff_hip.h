@@ -177,6 +177,11 @@ int laff_rank_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, cons
 int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* grp_off,
                    const int* grp_idx, int max_group, int* count);
 
+/* ---- result lists (predictor.txt2video_write_to_file, predictor.py:53-88): for every row the K best columns, score
+ * descending (ties: larger column first = a stable ascending argsort read backwards), instead of a full-matrix argsort.
+ * idx_out [Nt,K] int32, val_out [Nt,K] fp32.  1 <= K <= min(Nv, 2048); (Nv + K') * 8 bytes of LDS must fit 160 KiB. */
+int laff_topk_rows(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, int K, int* idx_out, float* val_out);
+
 /* ---- a13: evaluation.eval (evaluation.py:92-109) for single-GT rows ---------------------------------------
  * rank1[Nq] device int32, 1-based.  out7 (host) = r1, r5, r10, medr, meanr, mir, mAP.  Reduced on the device
  * (one small kernel), 56 bytes copied back; synchronises the stream. */

@@ -52,6 +52,7 @@ SIGNATURES = {
     'laff_row_dot_gt': (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P]),
     'laff_gather_gt': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P]),
     'laff_rank_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I]),
+    'laff_topk_rows': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
     'laff_v2t_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _I, _P]),
     'laff_rank_metrics': (C.c_int, [_P, _P, _I, C.POINTER(C.c_double)]),
     'laff_rank_metrics_async': (C.c_int, [_P, _P, _I, _P]),

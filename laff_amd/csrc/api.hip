@@ -375,6 +375,17 @@ int laff_rank_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, cons
     return LAFF_OK;
 }
 
+int laff_topk_rows(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, int K, int* idx_out, float* val_out) {
+    CHECK_CTX(ctx);
+    if (!S || !idx_out || !val_out) return fail(LAFF_E_ARG, "laff_topk_rows: null argument");
+    if (Nt < 0 || Nv < 1 || lds < Nv || K < 1 || K > Nv || K > 2048) return fail(LAFF_E_SHAPE, "laff_topk_rows: need 1 <= K <= min(Nv, 2048) (Nt=%d Nv=%d K=%d)", Nt, Nv, K);
+    if ((size_t)Nv * 4 + 2048 * 8 + 2048 > 160 * 1024) return fail(LAFF_E_UNSUPPORTED, "laff_topk_rows: Nv=%d does not fit the LDS-resident row (max ~36k columns per shard)", Nv);
+    if (Nt == 0) return LAFF_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_topk_rows(S, Nt, Nv, lds, K, idx_out, val_out, ctx->stream));
+    return LAFF_OK;
+}
+
 int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx,
                    int max_group, int* count) {
     CHECK_CTX(ctx);

@@ -93,6 +93,7 @@ hipError_t launch_gather_gt(const float* S, int Nt, int Nv, int lds, const int* 
                             hipStream_t st);
 hipError_t launch_rank_count(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, const float* s_gt,
                              int* count, int accumulate, hipStream_t st);
+hipError_t launch_topk_rows(const float* S, int Nt, int Nv, int lds, int K, int* idx_out, float* val_out, hipStream_t st);
 hipError_t launch_v2t_count(const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx,
                             int max_group, int* count, hipStream_t st);
 

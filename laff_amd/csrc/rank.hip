@@ -279,3 +279,123 @@ hipError_t launch_v2t_count(const float* S, int Nt, int Nv, int lds, const int* 
 }
 
 }  // namespace laff
+
+// ---- top-K per text row --------------------------------------------------------------------
+// The result writers of the reference (/root/reference/predictor.py:53-88) take `np.argsort(S, axis=1)[i][::-1][0:TopK]`
+// of every row (TopK = 500 / 2000).  Here: one 256-thread workgroup per row; the row lives in LDS as order-preserving
+// 32-bit keys; the K-th largest is found by an MSB-first radix select (4 passes of a 256-bin LDS histogram); the K
+// survivors are compacted and bitonic-sorted as 64-bit (key, index) pairs.  Order: score descending, ties by index
+// descending (what a stable ascending argsort read backwards yields).
+namespace laff {
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+// among elements i with pred(i), find the byte-wise prefix of the `need`-th largest value of val(i);
+// returns the full 32-bit value; *above = how many selected elements are strictly greater.
+template <typename Val, typename Pred>
+__device__ unsigned radix_select(int n, int need, Val val, Pred pred, unsigned* hist, int* sh, int* above_out) {
+    unsigned prefix = 0, mask = 0;
+    int above = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            if (pred(i)) {
+                const unsigned v = val(i);
+                if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255], 1u);
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) {              // 256 bins: a serial scan from the top is cheap enough
+            int acc = above, b = 255;
+            for (; b > 0; --b) {
+                if (acc + (int)hist[b] >= need) break;
+                acc += hist[b];
+            }
+            sh[0] = b;
+            sh[1] = acc;
+        }
+        __syncthreads();
+        prefix |= (unsigned)sh[0] << shift;
+        mask |= 255u << shift;
+        above = sh[1];
+        __syncthreads();
+    }
+    *above_out = above;
+    return prefix;
+}
+
+template <int KP /* power of two >= K */>
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ S, int Nv, long lds, int K,
+                                                        int* __restrict__ idx_out, float* __restrict__ val_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned* keys = (unsigned*)smem_raw;                               // [Nv]
+    unsigned long long* sel = (unsigned long long*)(keys + ((Nv + 3) & ~3));   // [KP]
+    unsigned* hist = (unsigned*)(sel + KP);                             // [256]
+    int* sh = (int*)(hist + 256);                                       // [4]
+    const long t = blockIdx.x;
+    const float* row = S + t * lds;
+    for (int i = threadIdx.x; i < Nv; i += 256) keys[i] = f2key(row[i]);
+    for (int i = threadIdx.x; i < KP; i += 256) sel[i] = 0ull;          // padding sorts last
+    __syncthreads();
+    int above = 0;
+    const unsigned T = radix_select(Nv, K, [&](int i) { return keys[i]; }, [](int) { return true; }, hist, sh, &above);
+    // ties at the threshold: take the (K - above) LARGEST indices among keys == T
+    const int need_eq = K - above;
+    int above_i = 0;
+    const unsigned Ti = radix_select(Nv, need_eq, [](int i) { return (unsigned)i; }, [&](int i) { return keys[i] == T; }, hist, sh, &above_i);
+    if (threadIdx.x == 0) sh[2] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < Nv; i += 256) {
+        const unsigned k = keys[i];
+        if (k > T || (k == T && (unsigned)i >= Ti)) {
+            const int p = atomicAdd(&sh[2], 1);
+            if (p < KP) sel[p] = ((unsigned long long)k << 32) | (unsigned)i;
+        }
+    }
+    __syncthreads();
+    // bitonic sort, descending, KP elements
+    for (int k2 = 2; k2 <= KP; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < KP; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = sel[i], b = sel[l];
+                    const bool desc = (i & k2) == 0;
+                    if (desc ? a < b : a > b) { sel[i] = b; sel[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < K; i += 256) {
+        const unsigned long long e = sel[i];
+        idx_out[t * K + i] = (int)(unsigned)e;
+        val_out[t * K + i] = key2f((unsigned)(e >> 32));
+    }
+}
+
+hipError_t launch_topk_rows(const float* S, int Nt, int Nv, int lds, int K, int* idx_out, float* val_out, hipStream_t st) {
+    if (K > 2048) return hipErrorInvalidValue;
+#define LAFF_TOPK(P)                                                                                                     \
+    do {                                                                                                                 \
+        const size_t smem = (size_t)((Nv + 3) & ~3) * 4 + (size_t)(P) * 8 + 256 * 4 + 16;                                  \
+        if (smem > 160 * 1024) return hipErrorInvalidValue;                                                              \
+        if (smem > 64 * 1024) {                                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)topk_rows_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+            if (e != hipSuccess) return e;                                                                               \
+        }                                                                                                                \
+        hipLaunchKernelGGL((topk_rows_kernel<P>), dim3(Nt), dim3(256), smem, st, S, Nv, (long)lds, K, idx_out, val_out);  \
+    } while (0)
+    if (K <= 64) LAFF_TOPK(64);
+    else if (K <= 512) LAFF_TOPK(512);
+    else LAFF_TOPK(2048);
+#undef LAFF_TOPK
+    return hipGetLastError();
+}
+
+}  // namespace laff

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, FcSplitProblem, Plane, check)
 
-__all__ = ['fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['topk_rows', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -348,6 +348,17 @@ def rank_count(S, gt_col, s_gt, col0=0, count=None):
     _call('rank_count', lib.laff_rank_count, h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(gt_col), col0, _ptr(s_gt), _ptr(count),
                               1 if acc else 0)
     return count
+
+
+def topk_rows(S, K):
+    """Per row: indices (int32) and scores (fp32) of the K best columns, score descending, ties by larger index first."""
+    S, lds = _rows(S, 'S')
+    Nt, Nv = S.shape
+    idx = torch.empty((Nt, K), device=S.device, dtype=torch.int32)
+    val = torch.empty((Nt, K), device=S.device, dtype=torch.float32)
+    lib, h = _context(S.device)
+    _call('topk_rows', lib.laff_topk_rows, h, _ptr(S), Nt, Nv, lds, int(K), _ptr(idx), _ptr(val))
+    return idx, val
 
 
 def v2t_count(S, grp_off, grp_idx, max_group):

@@ -77,3 +77,45 @@ def retrieval_metrics(S, txt_ids, vis_ids):
         S = torch.as_tensor(np.ascontiguousarray(S, dtype=np.float32), device='cuda')
     owner = gt_columns(txt_ids, vis_ids)
     return t2v_metrics(S, owner), v2t_metrics(S, owner)
+
+
+def topk_lists(S, vis_ids, Threshold=2000):
+    """(idx (Nt,K) int32, val (Nt,K) float32) numpy: the ranked lists the reference's writers keep per query
+    (predictor.py:55-65): the best `Threshold` videos when the collection has at least that many, else -- faithfully to
+    the reference's `inds[index][::-1][0:-1]` -- all but the last one.  Selected and sorted on the device."""
+    if not isinstance(S, torch.Tensor):
+        S = torch.as_tensor(np.ascontiguousarray(S, dtype=np.float32), device='cuda')
+    Nv = len(vis_ids)
+    K = Threshold if Nv >= Threshold else Nv - 1
+    if K < 1:
+        return np.zeros((S.shape[0], 0), np.int32), np.zeros((S.shape[0], 0), np.float32)
+    idx, val = ops.topk_rows(S, K)
+    return idx.cpu().numpy(), val.cpu().numpy()
+
+
+def txt2video_write_to_file(pred_result_file, S, vis_ids, txt_ids, pkl_saved_file=None, txt_loader=None, Threshold=2000):
+    """predictor.txt2video_write_to_file (predictor.py:53-88) fed by the device top-K instead of a full-matrix argsort:
+    `id.sent.score.txt` lines `txt_id vis_id score vis_id score ...` (scores printed as numpy float32, like the
+    reference) and the `t2v.pkl` dict {txt_id: {query, rank_list, sim_value}}."""
+    import pickle
+    idx, val = topk_lists(S, vis_ids, Threshold)
+    vis = np.asarray(vis_ids, dtype=object)
+    shot_dict = {}
+    fout = open(pred_result_file, 'w') if pred_result_file is not None else None
+    try:
+        for r in range(idx.shape[0]):
+            names = vis[idx[r]]
+            if fout is not None:
+                fout.write(txt_ids[r] + ' ' + ' '.join([n + ' %s' % v for n, v in zip(names, val[r])]) + '\n')
+            if pkl_saved_file is not None:
+                shot_dict[txt_ids[r]] = {
+                    'query': txt_loader.dataset.get_caption_dict_by_id(txt_ids[r])['caption'] if hasattr(txt_loader.dataset, 'get_caption_dict_by_id')
+                    else txt_loader.dataset.captions[txt_ids[r]],
+                    'rank_list': list(names), 'sim_value': list(val[r])}
+    finally:
+        if fout is not None:
+            fout.close()
+    if pkl_saved_file is not None:
+        with open(pkl_saved_file, 'wb') as f:
+            pickle.dump(shot_dict, f)
+    return idx, val

@@ -369,3 +369,42 @@ def test_fuse_emits_the_packed_operand():
         S1 = ops.sim_gemm(P, P, heads=H)
         S2 = ops.sim_gemm(Q, Q, heads=H)
         assert maxdiff(S1, S2) <= (1e-4 if prec == 'fp16' else 2e-3)
+
+
+@pytest.mark.parametrize('Nt,Nv,K', [(7, 30, 10), (50, 10000, 500), (9, 3000, 2000), (5, 33, 32), (3, 5, 1)])
+def test_topk_rows_vs_argsort(Nt, Nv, K):
+    from laff_amd import ops
+    g = rnd(Nt + Nv + K)
+    S = g.normal(0, 0.2, (Nt, Nv)).astype(np.float32)
+    S[0, :min(5, Nv)] = S[0, min(7, Nv - 1)]     # ties, some of them across the K boundary for small K
+    S[1 % Nt, -1] = np.float32(-0.0)
+    idx, val = ops.topk_rows(dev(S), K)
+    ref = np.argsort(S, axis=1, kind='stable')[:, ::-1][:, :K]
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(val.cpu().numpy(), np.take_along_axis(S, ref, axis=1))
+
+
+def test_result_writers_golden(golden, tmp_path):
+    """id.sent.score.txt and t2v.pkl byte-for-byte / value-for-value what the reference's writer produces."""
+    import pickle
+    from laff_amd import predictor
+    g = golden('writers')
+    S, vis_ids, txt_ids = dev(g['S']), g.json('vis_ids'), g.json('txt_ids')
+
+    class _DS:
+        def get_caption_dict_by_id(self, cid):
+            return {'caption': 'caption of ' + cid}
+
+    class _TL:
+        dataset = _DS()
+
+    for name, thr in (('top10', 10), ('all', 2000)):
+        f, pk = str(tmp_path / (name + '.txt')), str(tmp_path / (name + '.pkl'))
+        predictor.txt2video_write_to_file(f, S, vis_ids, txt_ids, pkl_saved_file=pk, txt_loader=_TL(), Threshold=thr)
+        assert open(f).read() == str(g[name + '/text'])
+        got = pickle.load(open(pk, 'rb'))
+        exp = g.json(name + '/pkl')
+        assert list(got.keys()) == list(exp.keys())
+        for k in exp:
+            assert got[k]['query'] == exp[k]['query'] and got[k]['rank_list'] == exp[k]['rank_list']
+            assert [repr(float(x)) for x in got[k]['sim_value']] == exp[k]['sim_value']

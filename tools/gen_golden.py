@@ -688,10 +688,49 @@ def gen_bigfile():
     print('wrote bigfile fixtures')
 
 
+# ----------------------------------------------------------------------------------------------
+# (11) result writers: predictor.txt2video_write_to_file (predictor.py:53-88)
+# ----------------------------------------------------------------------------------------------
+def gen_writers():
+    import pickle
+    import tempfile
+    import predictor as ref_predictor
+    g = rng(1111)
+    arrays = {}
+    Nt, Nv = 25, 30
+    S = f32(g.normal(0, 0.2, (Nt, Nv)))
+    S[3, 7] = S[3, 9]                       # an exact tie inside the kept range
+    vis_ids = ['video%d' % i for i in range(Nv)]
+    txt_ids = ['video%d#%d' % (i % Nv, i // Nv) for i in range(Nt)]
+
+    class _DS:
+        def get_caption_dict_by_id(self, cid):
+            return {'caption': 'caption of ' + cid}
+
+    class _TL:
+        dataset = _DS()
+
+    inds = np.argsort(S, axis=1, kind='stable')
+    for name, thr in (('top10', 10), ('all', 2000)):
+        with tempfile.TemporaryDirectory() as d:
+            f = os.path.join(d, 'id.sent.score.txt')
+            pk = os.path.join(d, 't2v.pkl')
+            ref_predictor.txt2video_write_to_file(f, inds, vis_ids, txt_ids, S, pkl_saved_file=pk, txt_loader=_TL(), Threshold=thr)
+            arrays[name + '/text'] = np.array(open(f).read())
+            dct = pickle.load(open(pk, 'rb'))
+            arrays[name + '/pkl'] = np.array(json.dumps({k: {'query': v['query'], 'rank_list': list(v['rank_list']),
+                                                             'sim_value': [repr(float(x)) for x in v['sim_value']]}
+                                                         for k, v in dct.items()}))
+    arrays['S'] = S
+    arrays['vis_ids'] = np.array(json.dumps(vis_ids))
+    arrays['txt_ids'] = np.array(json.dumps(txt_ids))
+    save('writers', **arrays)
+
+
 GENERATORS = {
     'attention_1': gen_attention_1, 'multi_head': gen_multi_head, 'transform_net': gen_transform_net,
     'laff_towers': gen_laff_towers, 'framelaff': gen_framelaff, 'txt2vis': gen_txt2vis,
-    'predict': gen_predict, 'eval': gen_eval, 'bigfile': gen_bigfile,
+    'predict': gen_predict, 'eval': gen_eval, 'bigfile': gen_bigfile, 'writers': gen_writers,
 }
 
 if __name__ == '__main__':
