@@ -140,6 +140,7 @@ def main():
     ap.add_argument('--fc-precision', default='fp16x3', help="FC projections: fp32 (fp32 MFMA) | fp16x3 (exact fp16 hi/lo split)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of HIP-graph replays')
+    ap.add_argument('--force-dist', action='store_true', help='run the N > 1 code path (collectives included) on a 1-rank group')
     ap.add_argument('--profile-steps', type=int, default=5, help='eager steps (after the timed region) for per-kernel events')
     ap.add_argument('--seed', type=int, default=1237)
     args = ap.parse_args()
@@ -147,7 +148,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or ('RANK' in os.environ and '--force-dist' in sys.argv):
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     if args.gpus != world:
@@ -174,40 +175,56 @@ def main():
     ops.profiler = prof
 
     metrics_pinned = torch.zeros(8, dtype=torch.float64).pin_memory()
+    force_dist = args.force_dist and dist.is_initialized()
+    distributed = world > 1 or force_dist
 
-    def step(timed, async_metrics=False):
+    def step(timed, async_metrics=False, runner=None, state=None):
         timer.enabled = timed
         prof.enabled = timed
         timer.start()
         return evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer,
-                                metrics_out=metrics_pinned if async_metrics else None)
+                                metrics_out=metrics_pinned if async_metrics else None, runner=runner, state=state,
+                                force_collectives=force_dist)
 
-    # The timed region replays ONE captured HIP graph per step (single GPU): the step is ~15 launches of 10-1000 us
-    # each, and eager Python issue (~0.3 ms per step) would otherwise sit on the critical path of every step because
-    # the step ends with a host sync (the 7 metrics).  Collectives are not captured: N > 1 runs eager.
-    graph = None
-    use_graph = (world == 1) and not args.no_graph
+    # Launch modes of the timed region (host issue of ~15 launches costs 0.3-0.4 ms per step, as much as the GPU work of a
+    # 1/4 shard, and sits on the critical path because every step ends with a host sync on the 7 metrics):
+    #   single GPU : ONE captured HIP graph per step;
+    #   N > 1      : one captured graph per LOCAL phase (laff_amd.dist.GraphRunner), the three RCCL collectives eager
+    #                between them -- nothing RCCL-related is ever captured;
+    #   --no-graph : eager launches.
+    graph, runner, state = None, None, {}
     for _ in range(max(1, args.warmup)):
         res = step(False)
     torch.cuda.synchronize()
-    if use_graph:
+    if not args.no_graph:
         try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                res = step(False, async_metrics=True)
-            graph.replay()
-            torch.cuda.synchronize()
+            if distributed:
+                from laff_amd.dist import GraphRunner
+                runner = GraphRunner()
+                res = step(False, async_metrics=True, runner=runner, state=state)      # captures + runs every phase once
+                torch.cuda.synchronize()
+            else:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    res = step(False, async_metrics=True)
+                graph.replay()
+                torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             print('warning: HIP graph capture failed (%s); timing eager launches' % e, file=sys.stderr)
-            graph = None
+            graph, runner = None, None
             torch.cuda.synchronize()
             res = step(False)
+    launch_mode = 'HIP graph replay' if graph is not None else ('per-phase HIP graphs + eager RCCL' if runner is not None else 'eager')
 
     def timed_step():
         if graph is not None:
             graph.replay()
             torch.cuda.current_stream().synchronize()     # the step's result (7 metrics) is on the host
             return None
+        if runner is not None:
+            r = step(False, async_metrics=True, runner=runner, state=state)
+            torch.cuda.current_stream().synchronize()
+            return r
         return step(True)        # eager: per-launch events are recorded inside the timed region
 
     if world > 1:
@@ -227,9 +244,10 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    if graph is not None:
+    if graph is not None or runner is not None:
         final_metrics = tuple(metrics_pinned[:7].tolist())
         # per-kernel durations: the same kernels on the same data, launched eagerly with events around each launch
+        # (every rank runs the same number of steps: the collectives stay matched)
         for _ in range(args.profile_steps):
             res = step(True)
         torch.cuda.synchronize()
@@ -317,7 +335,7 @@ def main():
             'config': {'workload': '%s: %d texts x %d videos, 4+4 features of 512-d, %d head(s) x d=%d' % (args.workload, Nt, Nv, heads, d),
                        'parallelism': 'video-row shards x%d, all-gather of text operand' % world if world > 1 else 'single GPU',
                        'scores': 'fp32 S materialised in HBM',
-                       'launch': 'HIP graph replay' if graph is not None else 'eager'},
+                       'launch': launch_mode},
             'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6],
                         'vs_strict_similarity': agreement},
             'stages_ms': {k: round(v, 4) for k, v in stages.items()},
@@ -328,7 +346,7 @@ def main():
             sn, sv = (Nt, Nv) if float(Nt) * Nv <= 4.0e8 else (40000, 10000)       # ~10-20 s of host work
             line['cpu_baseline'] = cpu_baseline(args.workload, sn, sv, heads, d, args.seed)
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

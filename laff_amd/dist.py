@@ -110,72 +110,117 @@ class HipBackend:
         ops.rank_metrics_async(ranks, out_pinned)
 
 
+class GraphRunner:
+    """Runs each LOCAL phase of evaluate_sharded as its own captured HIP graph (first call: capture + replay, later calls:
+    replay).  Collectives stay eager between the phases, so nothing RCCL-related is ever captured; what disappears is the
+    per-step Python/ctypes issue cost of ~15 kernel launches (0.3-0.4 ms, several times the GPU time of a 1/8 shard)."""
+
+    def __init__(self):
+        self.graphs, self.outs = {}, {}
+
+    def __call__(self, name, fn):
+        if name not in self.graphs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = fn()
+            self.graphs[name], self.outs[name] = g, out
+        self.graphs[name].replay()
+        return self.outs[name]
+
+
+def _eager(name, fn):
+    return fn()
+
+
 def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
-                     timer=None, want_scores=True, metrics_out=None):
+                     timer=None, want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False):
     """One pass of the hot path on this rank's shards.  gt: (Nt,) int32 GLOBAL video column of every text (replicated).
 
-    Returns dict(S_local (Nt, v1-v0), col0, ranks (Nt,), metrics)."""
+    runner: None (eager) or a GraphRunner; state: dict that persists across steps (static collective buffers) -- required
+    with a GraphRunner.  force_collectives runs the collectives even on a 1-rank group (used to exercise the N > 1 code
+    path on a single GPU).  Returns dict(S_local (Nt, v1-v0), col0, ranks (Nt,), metrics)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    comm = world > 1 or (force_collectives and dist.is_initialized())
     v0, v1 = shard_bounds(Nv, world, rank)
     mark = timer.mark if timer is not None else (lambda name: None)
+    run = runner if runner is not None else _eager
+    state = state if state is not None else {}
+    if runner is not None and metrics_out is None and want_metrics:
+        raise ValueError('a GraphRunner needs metrics_out (pinned buffer): the synchronising metrics call cannot be captured')
+    sizes = [shard_bounds(Nt, world, r) for r in range(world)]
+    nmax = max(hi - lo for lo, hi in sizes)
     with torch.no_grad():
-        vis_emb = None
-        if world == 1 and hasattr(compute, 'embed_both'):
-            vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local)
+        if not comm and hasattr(compute, 'embed_both'):
+            def towers():
+                vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local)
+                return (txt_emb, compute.pack(txt_emb, compute.txt_layer()), vis_emb, compute.pack(vis_emb, compute.vis_layer()))
+            txt_emb, T_all, vis_emb, V_local = run('towers', towers)
             mark('towers')
         else:
-            txt_emb = compute.embed_text(txt_feats_local)
-            mark('txt_tower')
-        T_local = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
-        mark('pack')
-        work = None
-        if world > 1:
-            if T_local.precision in ('fp16', 'bf16'):
-                sizes = [shard_bounds(Nt, world, r) for r in range(world)]
-                nmax = max(hi - lo for lo, hi in sizes)
+            def text_phase():
+                txt_emb = compute.embed_text(txt_feats_local)
+                T_local = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
+                if T_local.precision not in ('fp16', 'bf16'):
+                    raise NotImplementedError("sharded evaluation gathers a single-plane 16-bit operand; precision '%s' "
+                                              "is single-GPU only for now" % T_local.precision)
                 row_bytes = T_local.K * 2
                 send = T_local.buf[:T_local.N * row_bytes]
                 if T_local.N != nmax:       # equal-sized contributions for all_gather_into_tensor
                     pad = torch.zeros(nmax * row_bytes, dtype=torch.uint8, device=send.device)
                     pad[:send.numel()] = send
                     send = pad
-                gathered = torch.empty(world * nmax * row_bytes, dtype=torch.uint8, device=send.device)
-                work = dist.all_gather_into_tensor(gathered, send.contiguous(), group=group, async_op=True)
-            else:
-                raise NotImplementedError("sharded evaluation gathers a single-plane 16-bit operand; precision '%s' "
-                                          "is single-GPU only for now" % T_local.precision)
-        if vis_emb is None:
-            vis_emb = compute.embed_video(vis_feats_local)
+                return txt_emb, T_local, send.contiguous()
+            txt_emb, T_local, send = run('text', text_phase)
+            mark('txt_tower')
+            row_bytes = T_local.K * 2
+            work = None
+            if comm:
+                if 'gathered' not in state or state['gathered'].numel() != world * nmax * row_bytes:
+                    state['gathered'] = torch.empty(world * nmax * row_bytes, dtype=torch.uint8, device=send.device)
+                gathered = state['gathered']
+                work = dist.all_gather_into_tensor(gathered, send, group=group, async_op=True)     # overlaps the video tower
+
+            def video_phase():
+                vis_emb = compute.embed_video(vis_feats_local)
+                V = compute.pack(vis_emb, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack(vis_emb)
+                return vis_emb, V
+            vis_emb, V_local = run('video', video_phase)
             mark('vis_tower')
-        V_local = compute.pack(vis_emb, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack(vis_emb)
-        mark('pack')
-        if world > 1:
-            work.wait()
-            if all(hi - lo == nmax for lo, hi in sizes):
+            if work is None:
+                T_all = T_local
+            else:
+                work.wait()
+            if work is None:
+                pass
+            elif all(hi - lo == nmax for lo, hi in sizes):
                 T_all = compute.operand_from_gathered(gathered, Nt, T_local.K, T_local)
             else:
+                if runner is not None:
+                    raise NotImplementedError('uneven text shards need a compaction copy that is not captured; use eager mode')
                 parts = [gathered[r * nmax * row_bytes: r * nmax * row_bytes + (hi - lo) * row_bytes]
                          for r, (lo, hi) in enumerate(sizes)]
                 T_all = compute.operand_from_gathered(torch.cat(parts), Nt, T_local.K, T_local)
             mark('all_gather_wait')
-        else:
-            T_all = T_local
         # ground-truth score from the shard that owns the column, then one GEMM that writes S and counts ranks
-        s_gt = compute.row_dot_gt(T_all, V_local, gt, heads, v0)
-        if world > 1:
+        s_gt = run('s_gt', lambda: compute.row_dot_gt(T_all, V_local, gt, heads, v0))
+        if comm:
             dist.all_reduce(s_gt, op=dist.ReduceOp.MAX, group=group)
         mark('s_gt')
-        S_local, count = compute.sim_ranked(T_all, V_local, heads, gt, s_gt, v0, want_scores)
+        S_local, count = run('sim', lambda: compute.sim_ranked(T_all, V_local, heads, gt, s_gt, v0, want_scores))
         mark('sim_gemm')
-        if world > 1:
+        if comm:
             dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
-        ranks = count + 1
+
+        def finish():
+            ranks = count + 1
+            if metrics_out is not None:
+                compute.metrics_async(ranks, metrics_out)     # no host sync: the caller reads metrics_out after one
+            return ranks
+        ranks = run('finish', finish)
         mark('rank')
         metrics = None
-        if metrics_out is not None:
-            compute.metrics_async(ranks, metrics_out)     # no host sync: the caller reads metrics_out after one
-        elif want_metrics:
+        if metrics_out is None and want_metrics:
             metrics = compute.metrics(ranks)
         mark('metrics')
     return {'S_local': S_local, 'col0': v0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb}
