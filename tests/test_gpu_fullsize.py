@@ -158,3 +158,38 @@ def test_c4_video_to_text_positions():
     assert abs(m[0] - 100.0 * np.mean(first <= 1)) < 1e-9 and m[3] == np.floor(np.median(first))
     t2v = predictor.t2v_metrics(S, owner)
     np.testing.assert_allclose(t2v, res.metrics, rtol=1e-13)
+
+
+def test_distributed_path_on_one_rank_rccl_group():
+    """The N > 1 code path (all_gather of the text operand, all_reduce MAX / SUM, per-phase HIP graphs) on a 1-rank RCCL
+    group: same ranks, scores and metrics as the plain single-GPU pass."""
+    import socket
+    import torch.distributed as dist
+    from laff_amd import synth
+    from laff_amd.dist import GraphRunner, HipBackend, evaluate_sharded
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device(DEV)
+    Nt, Nv, H, d, _ = synth.WORKLOADS['c2_10kx3k']
+    model = synth.build_model(H, d, dev)
+    vis, txt, gt, _ = synth.make_features(Nt, Nv, dev)
+    backend = HipBackend(model, 'fp16')
+    ref = evaluate_sharded(backend, vis, txt, gt, Nt, Nv, H)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, world_size=1, rank=0, device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        eager = evaluate_sharded(backend, vis, txt, gt, Nt, Nv, H, force_collectives=True)
+        assert torch.equal(eager['ranks'], ref['ranks']) and torch.equal(eager['S_local'], ref['S_local'])
+        np.testing.assert_allclose(eager['metrics'], ref['metrics'], rtol=1e-13)
+        pinned = torch.zeros(8, dtype=torch.float64).pin_memory()
+        runner, state = GraphRunner(), {}
+        for _ in range(3):                       # capture, then two replays
+            out = evaluate_sharded(backend, vis, txt, gt, Nt, Nv, H, force_collectives=True, runner=runner, state=state,
+                                   metrics_out=pinned)
+            torch.cuda.synchronize()
+            assert torch.equal(out['ranks'], ref['ranks']) and torch.equal(out['S_local'], ref['S_local'])
+            np.testing.assert_allclose(pinned[:7].numpy(), ref['metrics'], rtol=1e-13)
+            assert pinned[7].item() == 0
+    finally:
+        dist.destroy_process_group()
