@@ -89,15 +89,17 @@ class LaunchProfiler:
         return out
 
 
-def cpu_baseline(workload, sample_nt, sample_nv, heads, d, seed):
+def cpu_baseline(workload, sample_nt, sample_nv, heads, d, seed, spec=None):
     """The oracle (numpy restatement of the reference, `oracle/`) timed on this host's cores on a bounded sample of the
     same workload, in the reference's own shape: batch-64 block loop with per-block re-normalisation
     (model/model.py:1057-1077), then argsort-free count ranks.  kind = "port"."""
     from laff_amd import synth
     from oracle import laff_oracle as O
     dev = torch.device('cuda:0')
-    model = synth.build_model(heads, d, dev, seed=seed)
-    vis, txt, gt, _ = synth.make_features(sample_nt, sample_nv, dev, seed=seed)
+    model = synth.build_model(heads, d, dev, seed=seed, spec=spec)
+    vis, txt, gt, _ = synth.make_features(sample_nt, sample_nv, dev, seed=seed, spec=spec)
+    vid_names = list(model.vis_net.opt.vid_feats)
+    vnt, tnt = list(model.vis_net.opt.vis_no_transform), list(model.txt_net.opt.txt_no_transform)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     vis_np, txt_np, gt_np = synth.to_numpy_dict(vis), synth.to_numpy_dict(txt), gt.cpu().numpy()
     enc = {'rnn_encoder': 'rnn_encoding', 'bow_encoder': 'bow_encoding', 'w2v_encoder': 'w2v_encoding',
@@ -111,12 +113,12 @@ def cpu_baseline(workload, sample_nt, sample_nv, heads, d, seed):
     att_t = O.attention_from_sd(sd, 'txt_net.attention_layer.', heads, False, False)
     vb = []
     for s in range(0, sample_nv, bs):
-        specs = [O.feature_spec(sd, 'vis_net.VisMutiTransformNet.%s.' % n, vis_np[n][s:s + bs], 'tanh', heads, False)
-                 for n in synth.VID_FEATS]
+        specs = [O.feature_spec(sd, 'vis_net.VisMutiTransformNet.%s.' % n, vis_np[n][s:s + bs], 'tanh', heads, n in vnt)
+                 for n in vid_names]
         vb.append((np.arange(s, min(sample_nv, s + bs)), O.fuse_tower(specs, att_v, heads)))
     tb = []
     for s in range(0, sample_nt, bs):
-        specs = [O.feature_spec(sd, 'txt_net.transform_layer.%s_transform.' % e, txt_np[enc[e]][s:s + bs], 'tanh', heads, False)
+        specs = [O.feature_spec(sd, 'txt_net.transform_layer.%s_transform.' % e, txt_np[enc[e]][s:s + bs], 'tanh', heads, e in tnt)
                  for e in names]
         tb.append((np.arange(s, min(sample_nt, s + bs)), O.fuse_tower(specs, att_t, heads)))
     S = O.predict_blocked(tb, vb, sample_nt, sample_nv)
@@ -161,12 +163,14 @@ def main():
     import laff_amd.model.model as M
     M.FC_PRECISION = args.fc_precision
     Nt, Nv, heads, d, frames = synth.WORKLOADS[args.workload]
-    model = synth.build_model(heads, d, dev, frames=frames, seed=args.seed)
-    vis, txt, gt, lens = synth.make_features(Nt, Nv, dev, frames=frames, seed=args.seed)
+    spec = synth.SPECS.get(args.workload)
+    model = synth.build_model(heads, d, dev, frames=frames, seed=args.seed, spec=spec)
+    vis, txt, gt, lens = synth.make_features(Nt, Nv, dev, frames=frames, seed=args.seed, spec=spec)
     t0, t1 = shard_bounds(Nt, world, rank)
     v0, v1 = shard_bounds(Nv, world, rank)
-    vis_l = {k: v[v0:v1].contiguous() for k, v in vis.items()}
-    txt_l = {k: v[t0:t1].contiguous() for k, v in txt.items()}
+    vis_l = {k: synth.slice_rows(v, v0, v1) for k, v in vis.items()}
+    txt_l = {k: synth.slice_rows(v, t0, t1) for k, v in txt.items()}
+    sparse_nnz = sum(int(v.values().numel()) for v in txt_l.values() if v.layout != torch.strided)
     del vis, txt
     backend = HipBackend(model, args.precision)
     timer = StageTimer()
@@ -264,14 +268,23 @@ def main():
         # ---- roofline of the dominant kernel: ALGORITHMIC work (SURVEY.md section 8d / DESIGN.md) / measured launch time
         K = heads * d
         nvl, ntl = v1 - v0, t1 - t0
-        feat, L = 512, 4
+        if spec is None:
+            fc_v, fc_t, raw_v, raw_t, gather_dims = [512] * 4, [512] * 4, 0, 0, []
+        else:    # FC'd dense features, no-transform (raw) feature widths, sparse (gather) vocabularies
+            fc_v = [dk for n, dk in spec['vid'].items() if n not in spec['vis_no_transform']]
+            raw_v = sum(dk for n, dk in spec['vid'].items() if n in spec['vis_no_transform'])
+            fc_t, raw_t, gather_dims = [], spec['txt']['CLIP'], [spec['txt']['bow']]
+        fc_macs = float(K) * (nvl * sum(fc_v) + ntl * sum(fc_t))
+        Lv, Lt = len(fc_v) + (1 if raw_v else 0), len(fc_t) + len(gather_dims) + (1 if raw_t else 0)
         launches = {k: (t / prof_steps, c // prof_steps) for k, (t, c) in prof.totals().items()}   # ms per step, launches per step
         x3 = 3 if args.precision.endswith('x3') else 1
         work = {   # entry point -> (bound, algorithmic units per step on this rank, peak, unit scale)
-            'fc_act_bn': ('mfma', 2.0 * feat * K * L * (ntl + nvl) * (3 if args.fc_precision == 'fp16x3' else 1),
+            'fc_act_bn': ('mfma', 2.0 * fc_macs * (3 if args.fc_precision == 'fp16x3' else 1),
                           MFMA_PEAK_TFLOPS['f16' if args.fc_precision == 'fp16x3' else 'f32'], 1e12, 'TFLOP/s'),
-            'split_rows': ('hbm', (4.0 + 4.0) * feat * L * (ntl + nvl), HBM_PEAK_GBS, 1e9, 'GB/s'),
-            'fuse': ('hbm', 4.0 * (ntl + nvl) * K * (L + 1), HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'split_rows': ('hbm', (4.0 + 4.0) * (nvl * sum(fc_v) + ntl * sum(fc_t)), HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'fuse': ('hbm', 4.0 * K * (nvl * (Lv + 1 - (1 if raw_v else 0)) + ntl * (Lt + 1 - (1 if raw_t else 0)))
+                     + 4.0 * (nvl * raw_v + ntl * raw_t), HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'fc_gather': ('hbm', 4.0 * K * (sum(gather_dims) + ntl) + 8.0 * sparse_nnz, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'pack_rows': ('hbm', (4.0 + 2.0 * (2 if x3 == 3 else 1)) * (ntl + nvl) * K, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'rank_count': ('hbm', 4.0 * Nt * nvl, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'gather_gt': ('hbm', 8.0 * Nt, HBM_PEAK_GBS, 1e9, 'GB/s'),
@@ -332,7 +345,11 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32 towers (FC on %s) + %s similarity' % ('fp32 MFMA' if args.fc_precision == 'fp32' else 'fp16 hi/lo split x3 MFMA', args.precision),
             'data': 'synthetic',
-            'config': {'workload': '%s: %d texts x %d videos, 4+4 features of 512-d, %d head(s) x d=%d' % (args.workload, Nt, Nv, heads, d),
+            'config': {'workload': '%s: %d texts x %d videos, %s, %d head(s) x d=%d' % (
+                           args.workload, Nt, Nv, '4+4 features of 512-d' if spec is None else
+                           'video %s (no FC: %s) + text %s (no FC: %s, bow sparse CSR)' % (spec['vid'], spec['vis_no_transform'],
+                                                                                         spec['txt'], spec['txt_no_transform']),
+                           heads, d),
                        'parallelism': 'video-row shards x%d, all-gather of text operand' % world if world > 1 else 'single GPU',
                        'scores': 'fp32 S materialised in HBM',
                        'launch': launch_mode},
@@ -344,7 +361,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             sn, sv = (Nt, Nv) if float(Nt) * Nv <= 4.0e8 else (40000, 10000)       # ~10-20 s of host work
-            line['cpu_baseline'] = cpu_baseline(args.workload, sn, sv, heads, d, args.seed)
+            line['cpu_baseline'] = cpu_baseline(args.workload, sn, sv, heads, d, args.seed, spec)
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()

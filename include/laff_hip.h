@@ -106,6 +106,13 @@ typedef struct {
 } laff_fc_split_problem;
 int laff_fc_act_bn_split_grouped(laff_ctx* ctx, const laff_fc_split_problem* problems /*host array*/, int count);
 
+/* a1 for a SPARSE input feature (bag-of-words, model/model.py:399-416): X given as CSR (indptr[N+1], indices[nnz],
+ * values[nnz] or NULL = all ones) over Dk columns; Wt = W^T [Dk, ldwt >= D] so that one vocabulary entry is one contiguous
+ * row.  Y[N,D] = bn(act(sum_j values_j * Wt[indices_j, :] + bias)).  D % 4 == 0, D <= 8192, 16-byte aligned Wt / Y rows. */
+int laff_fc_gather_act_bn(laff_ctx* ctx, const int* indptr, const int* indices, const float* values, int N, int Dk,
+                          const float* Wt, int ldwt, const float* bias, const float* bn_scale, const float* bn_shift, int D,
+                          int act, float* Y, int ldy);
+
 /* ---- a2-a6: stack + Multi_head_MyApply_Attention / Attention_1 / JustAverage ----------------------------
  * (model/model.py:1858-1876, :1663-1705; model/Attention.py:508-531, :78-105)
  * One feature plane per fused feature; nothing is stacked or tiled in memory.

@@ -38,6 +38,7 @@ SIGNATURES = {
     'laff_device_info': (C.c_int, [_P, C.POINTER(_I)]),
     'laff_fc_act_bn': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I]),
     'laff_fc_act_bn_grouped': (C.c_int, [_P, C.POINTER(FcProblem), _I]),
+    'laff_fc_gather_act_bn': (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I]),
     'laff_split_rows_bytes': (C.c_int, [_I, _I, C.POINTER(C.c_size_t)]),
     'laff_split_rows': (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     'laff_split_rows_grouped': (C.c_int, [_P, _I, C.POINTER(C.c_void_p), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I),

@@ -165,6 +165,22 @@ int laff_fc_act_bn_grouped(laff_ctx* ctx, const laff_fc_problem* problems, int c
     return LAFF_OK;
 }
 
+int laff_fc_gather_act_bn(laff_ctx* ctx, const int* indptr, const int* indices, const float* values, int N, int Dk,
+                          const float* Wt, int ldwt, const float* bias, const float* bn_scale, const float* bn_shift, int D,
+                          int act, float* Y, int ldy) {
+    CHECK_CTX(ctx);
+    if (!indptr || !indices || !Wt || !Y) return fail(LAFF_E_ARG, "laff_fc_gather_act_bn: null argument");
+    if (N < 0 || Dk < 1 || D < 4 || (D & 3) || D > 8192 || ldwt < D || (ldwt & 3) || ldy < D || (ldy & 3))
+        return fail(LAFF_E_SHAPE, "laff_fc_gather_act_bn: bad shape N=%d Dk=%d D=%d ldwt=%d ldy=%d", N, Dk, D, ldwt, ldy);
+    if (act < LAFF_ACT_NONE || act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fc_gather_act_bn: bad act %d", act);
+    if ((bn_scale == nullptr) != (bn_shift == nullptr)) return fail(LAFF_E_ARG, "laff_fc_gather_act_bn: bn_scale/bn_shift must come together");
+    if (!aligned16(Wt) || !aligned16(Y)) return fail(LAFF_E_ALIGN, "laff_fc_gather_act_bn: Wt / Y must be 16-byte aligned");
+    if (N == 0) return LAFF_OK;
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_fc_gather(indptr, indices, values, N, Dk, Wt, ldwt, bias, bn_scale, bn_shift, D, act, Y, ldy, ctx->stream));
+    return LAFF_OK;
+}
+
 int laff_split_rows_bytes(int N, int K, size_t* out) {
     if (!out || N < 0 || K < 1) return fail(LAFF_E_ARG, "laff_split_rows_bytes: bad args");
     const size_t Kp = (size_t)(K + 63) / 64 * 64;

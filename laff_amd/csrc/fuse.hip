@@ -598,3 +598,89 @@ hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int no
 }
 
 }  // namespace laff
+
+// ---- FC projection of a SPARSE feature ------------------------------------------------------
+// The bag-of-words text feature (/root/reference/model/model.py:399-416, txt2vec.py) is a count vector over a vocabulary
+// of thousands with ~10 non-zeros; `bow @ W^T` is then a weighted sum of ~10 columns of W.  One 256-thread workgroup per
+// caption gathers those rows of W^T [Dk, D] (16-byte loads, D contiguous), accumulates in registers and applies the
+// TransformNet epilogue (bias -> activation -> folded BN).  2*nnz*D flops instead of 2*Dk*D per row.
+namespace laff {
+
+__device__ __forceinline__ float gather_act(float v, int act) {
+    if (act == 1) return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v * 2.885390081777927f) + 1.0f);
+    if (act == 2) return fmaxf(v, 0.0f);
+    if (act == 3) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+    return v;
+}
+
+// Work decomposition: the output is cut into column chunks of 512 floats (128 lanes x float4); workgroup b handles chunk
+// b % nchunks of two captions.  Workgroups are dispatched round-robin over the 8 XCDs, so with nchunks == 8 (D = 4096)
+// XCD x only ever touches columns [512x, 512x+512) of W^T: its private 4 MiB L2 then holds the ~2,000 most frequent
+// vocabulary entries of that slice instead of the ~250 most frequent whole 16 KiB rows, and word frequencies are Zipfian.
+__global__ __launch_bounds__(256) void fc_gather_kernel(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                        const float* __restrict__ values, int N, int Dk, const float* __restrict__ Wt,
+                                                        long ldwt, const float* __restrict__ bias, const float* __restrict__ bn_scale,
+                                                        const float* __restrict__ bn_shift, int D, int nchunks, int act,
+                                                        float* __restrict__ Y, long ldy) {
+    const int chunk = blockIdx.x % nchunks;
+    const long n = (long)(blockIdx.x / nchunks) * 2 + (threadIdx.x >> 7);
+    const int c_real = chunk * 512 + (threadIdx.x & 127) * 4;
+    if (n >= N) return;                                        // wave-uniform (a wave never straddles two captions)
+    const bool live = c_real < D;                              // lanes past D stay in the wave (they feed v_readlane) but
+    const int c = live ? c_real : 0;                           // read column 0 and store nothing
+    const int beg = indptr[n], end = indptr[n + 1];
+    const int lane = threadIdx.x & 63;
+    float4 acc0 = make_float4(0, 0, 0, 0), acc1 = acc0;
+    const float* wcol = Wt + c;
+    // The caption's ids/values are fetched 64 at a time with ONE coalesced load per wave and then broadcast lane by lane
+    // (v_readlane): the row loads of W^T no longer wait on a dependent index load each, and 8 of them are in flight per lane.
+    for (int p0 = beg; p0 < end; p0 += 64) {
+        const int cnt = min(64, end - p0);
+        int wi = 0;
+        float vi = 0.0f;
+        if (lane < cnt) {
+            wi = indices[p0 + lane];
+            vi = values ? values[p0 + lane] : 1.0f;
+            if (wi < 0 || wi >= Dk) { wi = 0; vi = 0.0f; }     // ids outside the vocabulary contribute nothing
+        }
+        int j = 0;
+        for (; j < cnt; j += 8) {                               // lanes >= cnt hold (row 0, weight 0): the tail needs no branch
+            float4 r[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int w = __builtin_amdgcn_readlane(wi, j + u);
+                v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vi), j + u));
+                r[u] = *(const float4*)(wcol + (long)w * ldwt);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc0 = fma4(r[u], v[u], acc0);
+                acc1 = fma4(r[u + 1], v[u + 1], acc1);
+            }
+        }
+    }
+    float o[4] = {acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = o[e] + (bias ? bias[c + e] : 0.0f);
+        t = gather_act(t, act);
+        if (bn_scale) t = fmaf(t, bn_scale[c + e], bn_shift[c + e]);
+        o[e] = t;
+    }
+    typedef float gather_f32x4 __attribute__((ext_vector_type(4)));
+    if (live) __builtin_nontemporal_store(gather_f32x4{o[0], o[1], o[2], o[3]}, (gather_f32x4*)(Y + n * ldy + c));
+}
+
+hipError_t launch_fc_gather(const int* indptr, const int* indices, const float* values, int N, int Dk, const float* Wt, int ldwt,
+                            const float* bias, const float* bn_scale, const float* bn_shift, int D, int act, float* Y, int ldy,
+                            hipStream_t st) {
+    const int nchunks = (D + 511) / 512;
+    const long blocks = (long)((N + 1) / 2) * nchunks;
+    if (blocks > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fc_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, st, indptr, indices, values, N, Dk, Wt, (long)ldwt,
+                       bias, bn_scale, bn_shift, D, nchunks, act, Y, (long)ldy);
+    return hipGetLastError();
+}
+
+}  // namespace laff

@@ -83,6 +83,9 @@ hipError_t launch_frame_fuse(const FrameArgs& a, hipStream_t st);
 hipError_t launch_split_rows_grouped(int count, const float* const* X, const int* N, const int* K, const int* ldx, void* const* out,
                                      float* const* rscale, hipStream_t st);
 hipError_t launch_split_rows(const float* X, int N, int K, int ldx, int Kp, void* out, float* rscale, hipStream_t st);
+hipError_t launch_fc_gather(const int* indptr, const int* indices, const float* values, int N, int Dk, const float* Wt, int ldwt,
+                            const float* bias, const float* bn_scale, const float* bn_shift, int D, int act, float* Y, int ldy,
+                            hipStream_t st);
 hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,
                             int precision, void* out, hipStream_t st);
 

@@ -130,6 +130,14 @@ class TransformNet(nn.Module):
             shift = (shift + extra_shift).contiguous()
         return scale, shift
 
+    def weight_t(self):
+        """fc1.weight transposed ([D_k, D]: one vocabulary entry = one contiguous row), cached until the weight changes."""
+        w = self.fc1.weight
+        key = (w.data_ptr(), w._version)
+        if getattr(self, '_w_t', None) is None or self._w_t[0] != key:
+            self._w_t = (key, w.detach().t().contiguous())
+        return self._w_t[1]
+
     def weight_split(self):
         """fp16 hi/lo split of fc1.weight for FC_PRECISION == 'fp16x3', cached until the weight changes."""
         if FC_PRECISION != 'fp16x3':
@@ -144,8 +152,13 @@ class TransformNet(nn.Module):
         """(src, tile, scale, shift) for laff_fuse.  With an FC the projection either runs now or, when `pending`
         (a list) is given, is appended to it so that the caller launches all features' GEMMs as one grouped kernel."""
         _eval_only(self)
-        x = to_device_and_float16(x)
         scale, shift = self.bn_affine(extra_shift)
+        if self.fc1 is not None and x.layout == torch.sparse_csr:
+            # sparse feature (bag-of-words): gather-sum of columns of W instead of a dense N x |vocab| x D GEMM
+            y = ops.fc_gather_act_bn(x.to(device), self.weight_t(), self.fc1.bias.detach() if self.fc1.bias is not None else None,
+                                     scale, shift, self.activation_name)
+            return (y, False, None, None)
+        x = to_device_and_float16(x)
         if self.fc1 is not None:
             prob = dict(x=x, weight=self.fc1.weight.detach(), weight_split=self.weight_split(),
                         bias=self.fc1.bias.detach() if self.fc1.bias is not None else None,

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, FcSplitProblem, Plane, check)
 
-__all__ = ['topk_rows', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['topk_rows', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -124,6 +124,28 @@ def fc_act_bn_grouped(problems):
     lib, h = _context(problems[0]['x'].device)
     _call('fc_act_bn', lib.laff_fc_act_bn_grouped, h, arr, len(problems))
     return outs
+
+
+def fc_gather_act_bn(x_csr, weight_t, bias=None, bn_scale=None, bn_shift=None, activation=None):
+    """TransformNet on a sparse (torch CSR) feature matrix: gather-sum of rows of weight_t = W^T [Dk, D]."""
+    if x_csr.layout != torch.sparse_csr or not x_csr.is_cuda:
+        raise RuntimeError('x_csr must be a CUDA torch.sparse_csr tensor')
+    N, Dk = x_csr.shape
+    wt, ldwt = _rows(weight_t, 'weight_t')
+    if wt.shape[0] != Dk:
+        raise ValueError('weight_t is %s but x has %d columns' % (tuple(wt.shape), Dk))
+    D = wt.shape[1]
+    crow = x_csr.crow_indices().to(torch.int32).contiguous()
+    col = x_csr.col_indices().to(torch.int32).contiguous()
+    val = x_csr.values().to(torch.float32).contiguous()
+    for t, nm in ((bias, 'bias'), (bn_scale, 'bn_scale'), (bn_shift, 'bn_shift')):
+        if t is not None:
+            _dev(t, nm)
+    out = torch.empty((N, D), device=wt.device, dtype=torch.float32)
+    lib, h = _context(wt.device)
+    _call('fc_gather', lib.laff_fc_gather_act_bn, h, _ptr(crow), _ptr(col), _ptr(val), N, Dk, _ptr(wt), ldwt, _ptr(bias),
+          _ptr(bn_scale), _ptr(bn_shift), D, ACT[activation], _ptr(out), D)
+    return out
 
 
 class SplitOperand:

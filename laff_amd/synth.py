@@ -14,9 +14,20 @@ WORKLOADS = {
     'c3_framelaff_10kx3k': (10000, 3000, 1, 512, 32),
     'c4_40kx10k': (40000, 10000, 1, 512, 0),
     'c5_ml_100kx30k': (100000, 30000, 8, 512, 0),
+    'c1_test3k': (59800, 2990, 8, 512, 0),       # MSR-VTT test3k shapes: 2,990 videos x 20 captions, see SPECS
+    'tiny_c1': (600, 30, 8, 64, 0),
     'tiny': (512, 192, 1, 512, 0),
     'tiny_ml': (384, 128, 8, 512, 0),
     'tiny_frame': (256, 96, 1, 512, 8),
+}
+#: workloads whose features are not the uniform 4+4 x feat_dim set.  configs/laff.py of the reference: D = 8 x 512, the
+#: fine-tuned CLIP feature of both sides skips the FC (no_transform: tiled over heads + BatchNorm), bow is a sparse count
+#: vector over the caption vocabulary (gather-sum FC), gt(t) = t // 20 (every video has 20 consecutive captions).
+SPECS = {
+    'c1_test3k': dict(vid={'clip_ft': 512, 'x3d': 2048}, vis_no_transform=['clip_ft'], txt={'bow': 7811, 'CLIP': 512},
+                      txt_no_transform=['CLIP_encoder'], bow_nnz=(4, 24), caps_per_video=20),
+    'tiny_c1': dict(vid={'clip_ft': 64, 'x3d': 96}, vis_no_transform=['clip_ft'], txt={'bow': 333, 'CLIP': 64},
+                    txt_no_transform=['CLIP_encoder'], bow_nnz=(1, 9), caps_per_video=20),
 }
 VID_FEATS = ('clip_ft', 'x3d', 'ircsn', 'tf')
 TXT_FEATS = ('bow', 'w2v', 'rnn', 'CLIP')       # encoder order in the tower: rnn, bow, w2v, CLIP
@@ -24,8 +35,79 @@ TXT_KEY = {'bow': 'bow_encoding', 'w2v': 'w2v_encoding', 'rnn': 'rnn_encoding', 
 LATENT = 64
 
 
-def build_model(heads, d, device, frames=0, feat_dim=512, seed=1234):
-    """'LAFF' (or 'FrameLAFF') with 4 video + 4 text features of `feat_dim`; every feature goes through FC->tanh."""
+def _randomise_bn(model, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm1d):
+            n = m.num_features
+            m.weight.data.copy_(torch.empty(n).uniform_(0.5, 1.5, generator=g))
+            m.bias.data.copy_(torch.empty(n).normal_(0, 0.1, generator=g))
+            m.running_mean.data.copy_(torch.empty(n).normal_(0, 0.1, generator=g))
+            m.running_var.data.copy_(torch.empty(n).uniform_(0.5, 1.5, generator=g))
+
+
+def build_spec_model(spec, heads, d, device, seed=1234):
+    """'LAFF' with the feature set of SPECS[...] (mixed dims, no-transform CLIP features, sparse bow)."""
+    cfg = make_config(spec['vid'], spec['txt'], heads * d, heads, 'LAFF', vis_no_transform=spec['vis_no_transform'],
+                      txt_no_transform=spec['txt_no_transform'], batch_norm=True)
+    torch.manual_seed(seed)
+    model = get_model('LAFF', device, cfg).eval()
+    _randomise_bn(model, seed + 1)
+    # the two CLIP features live in one space (fine-tuned jointly): share their BatchNorm and the attention parameters so
+    # that the planted latent survives the random-init towers; the x3d / bow branches stay independent (they act as noise)
+    model.txt_net.transform_layer.CLIP_encoder_transform.load_state_dict(
+        getattr(model.vis_net.VisMutiTransformNet, spec['vis_no_transform'][0]).state_dict())
+    model.txt_net.attention_layer.load_state_dict(model.vis_net.attention_layer.state_dict())
+    return model
+
+
+def make_spec_features(spec, Nt, Nv, device, seed=1234, noise=None, sparse_bow=True):
+    """(vis{name: (Nv, D_k)}, txt{key: (Nt, D_k)}, gt).  bow is a torch CSR matrix (int32 indices) unless sparse_bow=False."""
+    import os
+    if noise is None:
+        noise = float(os.environ.get('LAFF_SYNTH_NOISE', '1.6'))
+    g = torch.Generator(device=device).manual_seed(seed)
+
+    def randn(*shape):
+        return torch.randn(*shape, generator=g, device=device, dtype=torch.float32)
+
+    zv = randn(Nv, LATENT)
+    gt = torch.clamp(torch.arange(Nt, device=device, dtype=torch.int64) // spec['caps_per_video'], max=Nv - 1)
+    zt = zv[gt]
+    vis, txt = {}, {}
+    clip_dim = spec['txt']['CLIP']
+    P_clip = randn(LATENT, clip_dim) / LATENT ** 0.5
+    for n, dim in spec['vid'].items():
+        P = P_clip if n in spec['vis_no_transform'] else randn(LATENT, dim) / LATENT ** 0.5
+        vis[n] = zv @ P + noise * randn(Nv, dim)
+    txt['CLIP_encoding'] = zt @ P_clip + noise * randn(Nt, clip_dim)
+    # bag of words: nnz distinct word ids per caption (Zipf-like popularity), counts 1 or 2
+    vocab = spec['txt']['bow']
+    lo, hi = spec['bow_nnz']
+    nnz = torch.randint(lo, hi + 1, (Nt,), generator=g, device=device)
+    crow = torch.zeros(Nt + 1, dtype=torch.int64, device=device)
+    crow[1:] = torch.cumsum(nnz, 0)
+    total = int(crow[-1])
+    u = torch.rand(total, generator=g, device=device)
+    col = torch.clamp((vocab ** u - 1.0).to(torch.int64), 0, vocab - 1)          # log-uniform ~ Zipf popularity
+    val = 1.0 + (torch.rand(total, generator=g, device=device) < 0.1).to(torch.float32)
+    row = torch.repeat_interleave(torch.arange(Nt, device=device), nnz)
+    dense = torch.zeros((Nt, vocab), dtype=torch.float32, device=device)
+    dense.index_put_((row, col), val, accumulate=True)                            # repeated ids add up, as a count vector does
+    if sparse_bow:
+        sp = dense.to_sparse_csr()
+        txt['bow_encoding'] = torch.sparse_csr_tensor(sp.crow_indices().to(torch.int32), sp.col_indices().to(torch.int32),
+                                                      sp.values(), size=sp.shape)
+    else:
+        txt['bow_encoding'] = dense
+    return vis, txt, gt.to(torch.int32), None
+
+
+def build_model(heads, d, device, frames=0, feat_dim=512, seed=1234, spec=None):
+    """'LAFF' (or 'FrameLAFF') with 4 video + 4 text features of `feat_dim`; every feature goes through FC->tanh.
+    spec: a SPECS entry for a non-uniform feature set."""
+    if spec is not None:
+        return build_spec_model(spec, heads, d, device, seed)
     D = heads * d
     vid = {n: feat_dim for n in VID_FEATS}
     txt = {n: feat_dim for n in TXT_FEATS}
@@ -48,20 +130,15 @@ def build_model(heads, d, device, frames=0, feat_dim=512, seed=1234):
         for tm, vm in zip(txt_mods, vis_mods):
             tm.load_state_dict(vm.state_dict())
         model.txt_net.attention_layer.load_state_dict(model.vis_net.attention_layer.state_dict())
-    g = torch.Generator(device='cpu').manual_seed(seed + 1)
-    for m in model.modules():
-        if isinstance(m, nn.BatchNorm1d):
-            n = m.num_features
-            m.weight.data.copy_(torch.empty(n).uniform_(0.5, 1.5, generator=g))
-            m.bias.data.copy_(torch.empty(n).normal_(0, 0.1, generator=g))
-            m.running_mean.data.copy_(torch.empty(n).normal_(0, 0.1, generator=g))
-            m.running_var.data.copy_(torch.empty(n).uniform_(0.5, 1.5, generator=g))
+    _randomise_bn(model, seed + 1)
     return model
 
 
-def make_features(Nt, Nv, device, frames=0, feat_dim=512, seed=1234, noise=None):
+def make_features(Nt, Nv, device, frames=0, feat_dim=512, seed=1234, noise=None, spec=None):
     """Returns (vis_feats{name: (Nv, D_k)} or frame tensors, txt_feats{key: (Nt, D_k)}, gt int32 (Nt,), lens|None)."""
     import os
+    if spec is not None:
+        return make_spec_features(spec, Nt, Nv, device, seed, noise)
     if noise is None:
         noise = float(os.environ.get('LAFF_SYNTH_NOISE', '1.6'))
     g = torch.Generator(device=device).manual_seed(seed)
@@ -99,5 +176,15 @@ def make_features(Nt, Nv, device, frames=0, feat_dim=512, seed=1234, noise=None)
     return vis, txt, gt.to(torch.int32), lens
 
 
+def slice_rows(x, lo, hi):
+    """Rows [lo, hi) of a dense tensor or of a CSR matrix (the rank's shard of a feature)."""
+    if x.layout == torch.strided:
+        return x[lo:hi].contiguous()
+    crow, col, val = x.crow_indices(), x.col_indices(), x.values()
+    a, b = int(crow[lo]), int(crow[hi])
+    return torch.sparse_csr_tensor((crow[lo:hi + 1] - a).to(crow.dtype), col[a:b].contiguous(), val[a:b].contiguous(),
+                                   size=(hi - lo, x.shape[1]))
+
+
 def to_numpy_dict(d):
-    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+    return {k: (v.to_dense() if v.layout != torch.strided else v).detach().cpu().numpy() for k, v in d.items()}

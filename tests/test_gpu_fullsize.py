@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import laff_oracle as O
+
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
@@ -193,3 +195,62 @@ def test_distributed_path_on_one_rank_rccl_group():
             assert pinned[7].item() == 0
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------- C1: MSR-VTT test3k shapes
+def _c1(name):
+    from laff_amd import synth
+    Nt, Nv, H, d, _ = synth.WORKLOADS[name]
+    spec = synth.SPECS[name]
+    dev = torch.device(DEV)
+    model = synth.build_model(H, d, dev, spec=spec)
+    vis, txt, gt, _ = synth.make_features(Nt, Nv, dev, spec=spec)
+    return model, vis, txt, gt, Nt, Nv, H
+
+
+def test_c1_small_whole_path_vs_oracle():
+    """2+2 features, no-transform CLIP (tiled over 8 heads + BN), sparse bow through the gather FC, 20 captions per video."""
+    from util import oracle_towers
+    from laff_amd import retrieval, synth
+    model, vis, txt, gt, Nt, Nv, H = _c1('tiny_c1')
+    res = retrieval.evaluate(model, vis, txt, gt, precision='fp32')
+    ve, te = oracle_towers(model, synth.to_numpy_dict(vis), synth.to_numpy_dict(txt))
+    assert np.abs(res.vis_emb.cpu().numpy() - ve).max() <= 1e-5
+    assert np.abs(res.txt_emb.cpu().numpy() - te).max() <= 1e-5
+    S = O.txt2vis_matrix(te, ve)
+    assert np.abs(res.S.cpu().numpy() - S).max() <= 1e-5
+    gtn = gt.cpu().numpy()
+    assert gtn.max() == Nv - 1 and np.all(np.bincount(gtn) == 20)
+    from laff_amd import predictor as P
+    txt_ids = ['v%d#%d' % (i // 20, i % 20) for i in range(Nt)]
+    vis_ids = ['v%d' % i for i in range(Nv)]
+    t2v_ref, v2t_ref = O.predictor_metrics(S, txt_ids, vis_ids)
+    t2v, v2t = P.retrieval_metrics(res.S, txt_ids, vis_ids)
+    assert np.allclose(t2v, res.metrics, rtol=1e-6)
+    assert np.allclose(t2v, t2v_ref, rtol=1e-3, atol=0.2)       # 1-ulp score flips move at most one query per bucket
+    assert np.allclose(v2t, v2t_ref, rtol=1e-3, atol=3.4)       # 30 videos: one flip = 3.3 pp
+
+
+def test_c1_test3k_shapes_sparse_bow_equals_dense_and_oracle_sample():
+    from util import oracle_towers
+    from laff_amd import retrieval, synth
+    model, vis, txt, gt, Nt, Nv, H = _c1('c1_test3k')
+    assert (Nt, Nv, H) == (59800, 2990, 8)
+    res = retrieval.evaluate(model, vis, txt, gt, precision='fp16')
+    # the dense formulation of the same bow matrix (what the reference computes) gives the same text embeddings
+    txt_dense = dict(txt, bow_encoding=txt['bow_encoding'].to_dense())
+    res_d = retrieval.evaluate(model, vis, txt_dense, gt, precision='fp16')
+    assert (res.txt_emb - res_d.txt_emb).abs().max().item() <= 2e-5
+    assert (res.ranks == res_d.ranks).float().mean().item() >= 0.999
+    # oracle on all videos and a sample of captions
+    rows = np.arange(0, Nt, 299)
+    ve, te = oracle_towers(model, synth.to_numpy_dict(vis), {k: v for k, v in synth.to_numpy_dict(txt).items()}, rows_t=rows)
+    assert np.abs(res.vis_emb.cpu().numpy() - ve).max() <= 1e-5
+    assert np.abs(res.txt_emb[torch.as_tensor(rows, device=DEV)].cpu().numpy() - te).max() <= 1e-5
+    S = O.txt2vis_matrix(te, ve)
+    assert np.abs(res.S[torch.as_tensor(rows, device=DEV)].cpu().numpy() - S).max() <= 1e-4
+    strict = retrieval.evaluate(model, vis, txt, gt, precision='fp16x3')
+    assert (strict.S - res.S).abs().max().item() <= 1e-4
+    for a, b in zip(res.metrics[:3], strict.metrics[:3]):
+        assert abs(a - b) <= 0.02
+    assert res.metrics[0] > 5.0                                  # far above chance (0.03 %)

@@ -408,3 +408,59 @@ def test_result_writers_golden(golden, tmp_path):
         for k in exp:
             assert got[k]['query'] == exp[k]['query'] and got[k]['rank_list'] == exp[k]['rank_list']
             assert [repr(float(x)) for x in got[k]['sim_value']] == exp[k]['sim_value']
+
+
+# ---------------------------------------------------------------------------------------------- a1, sparse input (bow)
+def _random_csr(g, N, Dk, max_nnz):
+    rows = []
+    for _ in range(N):
+        k = int(g.integers(0, max_nnz + 1))                       # empty captions included
+        ids = np.sort(g.choice(Dk, size=min(k, Dk), replace=False))
+        rows.append((ids, g.integers(1, 4, size=ids.size).astype(np.float32)))
+    crow = np.zeros(N + 1, np.int32)
+    crow[1:] = np.cumsum([len(r[0]) for r in rows])
+    col = np.concatenate([r[0] for r in rows]).astype(np.int32) if N else np.zeros(0, np.int32)
+    val = np.concatenate([r[1] for r in rows]).astype(np.float32) if N else np.zeros(0, np.float32)
+    dense = np.zeros((N, Dk), np.float32)
+    for i, (ids, v) in enumerate(rows):
+        dense[i, ids] = v
+    return crow, col, val, dense
+
+
+@pytest.mark.parametrize('N,Dk,D', [(1, 4, 4), (33, 333, 512), (130, 7811, 4096), (64, 1000, 2048), (17, 50, 260), (9, 77, 8192)])
+@pytest.mark.parametrize('act,bn', [('tanh', True), (None, False), ('relu', True), ('sigmoid', False)])
+def test_fc_gather_vs_oracle_on_densified_input(N, Dk, D, act, bn):
+    from laff_amd import ops
+    g = rnd(N * 5 + D)
+    crow, col, val, dense = _random_csr(g, N, Dk, 24)
+    W = (g.normal(0, 1, (D, Dk)) / 4).astype(np.float32)
+    b = g.normal(0, 0.1, D).astype(np.float32)
+    scale = g.uniform(0.5, 1.5, D).astype(np.float32) if bn else None
+    shift = g.normal(0, 0.1, D).astype(np.float32) if bn else None
+    x = torch.sparse_csr_tensor(dev(crow, torch.int32), dev(col, torch.int32), dev(val), size=(N, Dk))
+    y = ops.fc_gather_act_bn(x, dev(W.T), dev(b), dev(scale) if bn else None, dev(shift) if bn else None, act)
+    ref = O.transform_net(dense, W, b, act, None)                 # the reference densifies bow and runs nn.Linear
+    if bn:
+        ref = ref * scale + shift
+    assert maxdiff(y, ref) <= 1e-5
+    # and it agrees with the dense FC kernel on the same (densified) input
+    yd = ops.fc_act_bn(dev(dense), dev(W), dev(b), dev(scale) if bn else None, dev(shift) if bn else None, act)
+    assert maxdiff(y, yd) <= 1e-5
+
+
+def test_fc_gather_ignores_out_of_vocabulary_ids_and_rejects_bad_shapes():
+    from laff_amd import ops
+    g = rnd(3)
+    Dk, D = 40, 64
+    W = g.normal(0, 1, (D, Dk)).astype(np.float32)
+    crow = np.array([0, 3, 3, 5], np.int32)
+    col = np.array([1, 39, 7, 0, 2], np.int32)
+    val = np.ones(5, np.float32)
+    x = torch.sparse_csr_tensor(dev(crow, torch.int32), dev(col, torch.int32), dev(val), size=(3, Dk))
+    y = ops.fc_gather_act_bn(x, dev(W.T))
+    ref = np.stack([W[:, [1, 39, 7]].sum(1), np.zeros(D, np.float32), W[:, [0, 2]].sum(1)])
+    assert maxdiff(y, ref) <= 1e-5
+    with pytest.raises(ValueError):
+        ops.fc_gather_act_bn(x, dev(W.T[:30]))
+    with pytest.raises(RuntimeError):
+        ops.fc_gather_act_bn(dev(np.zeros((3, Dk), np.float32)), dev(W.T))

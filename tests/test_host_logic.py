@@ -115,3 +115,21 @@ def test_training_mode_and_out_of_scope_models_fail_loudly():
     m.train()
     with pytest.raises(NotImplementedError):
         m.vis_net({'a': torch.zeros(2, 16)})
+
+
+def test_spec_workload_features_and_csr_row_shards():
+    """C1-shaped synthetic features on the CPU: bow is CSR with int32 indices, 20 captions per video, shards re-assemble."""
+    import torch
+    from laff_amd import synth
+    spec = synth.SPECS['tiny_c1']
+    Nt, Nv = 600, 30
+    vis, txt, gt, _ = synth.make_spec_features(spec, Nt, Nv, torch.device('cpu'))
+    bow = txt['bow_encoding']
+    assert bow.layout == torch.sparse_csr and bow.crow_indices().dtype == torch.int32 and bow.shape == (Nt, spec['txt']['bow'])
+    assert vis['clip_ft'].shape == (Nv, 64) and vis['x3d'].shape == (Nv, 96) and txt['CLIP_encoding'].shape == (Nt, 64)
+    assert torch.equal(gt, (torch.arange(Nt) // 20).to(torch.int32))
+    dense = bow.to_dense()
+    assert dense.min() >= 0 and (dense.sum(1) >= 1).all()
+    parts = [synth.slice_rows(bow, lo, hi).to_dense() for lo, hi in ((0, 1), (1, 250), (250, 600))]
+    assert torch.equal(torch.cat(parts), dense)
+    assert torch.equal(synth.slice_rows(vis['x3d'], 3, 9), vis['x3d'][3:9])
