@@ -185,62 +185,123 @@ __device__ __forceinline__ int block_sum_int(int v, int* sh) {
     return t;
 }
 
+// The median is an order statistic of small positive integers: MSB-first radix select with 12-bit digits, starting at the
+// top set bit of the largest rank (two passes for ranks < 2^24), on ranks cached in registers.  (A first version bisected on
+// the value: 14 rounds of compare + block reduction, 68 us for 40,000 ranks -- 5 % of a whole C4 step.)
 __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, double* __restrict__ out7,
                                                             int* __restrict__ err) {
     __shared__ double sh[16];
     __shared__ int shi[16];
-    constexpr int PER = 64;                 // up to 65536 ranks live in registers for the bisection
+    __shared__ unsigned hist[4096];
+    __shared__ int sel[2];
+    constexpr int PER = 64;                 // up to 65536 ranks live in registers
     const bool in_regs = n <= PER * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int vals[PER];
     double c1 = 0, c5 = 0, c10 = 0, sum = 0, isum = 0;
     int mx = 0, mn = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const int i = j * 1024 + threadIdx.x;
-        vals[j] = (in_regs && i < n) ? r[i] : 0x7fffffff;      // sentinel never counts as <= mid
+        const int i = j * 1024 + tid;
+        vals[j] = (in_regs && i < n) ? r[i] : -1;              // -1 = no element
     }
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const int v = r[i];
-        c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
-        sum += v; isum += 1.0 / (double)v;
-        mx = max(mx, v); mn = min(mn, v);
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int v = vals[j];
+            if (v != -1) {
+                c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
+                sum += v; isum += 1.0 / (double)v;
+                mx = max(mx, v); mn = min(mn, v);
+            }
+        }
+    } else {
+        for (int i = tid; i < n; i += 1024) {
+            const int v = r[i];
+            c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
+            sum += v; isum += 1.0 / (double)v;
+            mx = max(mx, v); mn = min(mn, v);
+        }
     }
     c1 = block_sum(c1, sh); c5 = block_sum(c5, sh); c10 = block_sum(c10, sh);
     sum = block_sum(sum, sh); isum = block_sum(isum, sh);
     mx = block_max(mx, sh);
     mn = -block_max(-mn, sh);
-    // k-th smallest (0-based k = n/2) by bisection on the value: smallest v with #{r <= v} >= k+1
+    if (mn < 1) {                                               // invalid input: report, do not select
+        if (tid == 0) err[0] = 1;
+        return;
+    }
+    // k-th smallest (0-based k = n/2)
     const int k = n / 2;
-    int lo = mn, hi = mx;
-    while (lo < hi) {
-        const int mid = lo + (hi - lo) / 2;
-        int c = 0;
+    unsigned prefix = 0, mask = 0;
+    int less = 0;                                               // #{v < current prefix range}
+    for (int top = 32 - __clz(mx); top > 0; top -= 12) {
+        const int shift = max(0, top - 12), nb = 1 << (top - shift);
+        for (int i = tid; i < nb; i += 1024) hist[i] = 0;
+        __syncthreads();
+        auto tally = [&](int v) {
+            if (((unsigned)v & mask) == prefix) atomicAdd(&hist[((unsigned)v >> shift) & (nb - 1)], 1u);
+        };
         if (in_regs) {
 #pragma unroll
-            for (int j = 0; j < PER; ++j) c += vals[j] <= mid;
+            for (int j = 0; j < PER; ++j)
+                if (vals[j] != -1) tally(vals[j]);
         } else {
-            for (int i = threadIdx.x; i < n; i += 1024) c += r[i] <= mid;
+            for (int i = tid; i < n; i += 1024) tally(r[i]);
         }
-        c = block_sum_int(c, shi);
-        if (c >= k + 1) hi = mid; else lo = mid + 1;
+        __syncthreads();
+        // thread t owns bins [4t, 4t+4): block-wide exclusive scan of the per-thread sums, then the owner of k publishes
+        unsigned h[4], own = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (4 * tid + e < nb) ? hist[4 * tid + e] : 0u;
+            own += h[e];
+        }
+        int inc = (int)own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) shi[wave] = inc;
+        __syncthreads();
+        int before = less + inc - (int)own;
+        for (int w = 0; w < wave; ++w) before += shi[w];
+        if (before <= k && k < before + (int)own) {             // exactly one thread
+            int e = 0;
+            while (before + (int)h[e] <= k) { before += (int)h[e]; ++e; }
+            sel[0] = 4 * tid + e;
+            sel[1] = before;
+        }
+        __syncthreads();
+        prefix |= (unsigned)sel[0] << shift;
+        mask |= (unsigned)(nb - 1) << shift;
+        less = sel[1];
+        __syncthreads();
     }
+    const int lo = (int)prefix;
     double med = lo;
     if ((n & 1) == 0) {
         // sorted[k-1]: equals sorted[k] unless exactly k elements are smaller, then it is the largest of those
-        int cl = 0, below = 0;
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            const int v = r[i];
-            if (v < lo) { cl += 1; below = max(below, v); }
+        int below = 0;
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (vals[j] != -1 && vals[j] < lo) below = max(below, vals[j]);
+        } else {
+            for (int i = tid; i < n; i += 1024) {
+                const int v = r[i];
+                if (v < lo) below = max(below, v);
+            }
         }
-        cl = block_sum_int(cl, shi);
         below = block_max(below, sh);
-        const double prev = (cl >= k) ? (double)below : (double)lo;
+        const double prev = (less >= k) ? (double)below : (double)lo;
         med = 0.5 * (med + prev);
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         out7[0] = 100.0 * (c1 / n); out7[1] = 100.0 * (c5 / n); out7[2] = 100.0 * (c10 / n);
         out7[3] = floor(med); out7[4] = sum / n; out7[5] = isum / n; out7[6] = isum / n;
-        err[0] = mn < 1 ? 1 : 0;
+        err[0] = 0;
     }
 }
 

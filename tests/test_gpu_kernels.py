@@ -308,12 +308,14 @@ def test_fc_grouped_equals_single():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 10, 1001, 40000])
-def test_rank_metrics_device_vs_numpy(n):
+@pytest.mark.parametrize('n,hi', [(1, 3000), (2, 3000), (3, 3000), (10, 3000), (1001, 3000), (40000, 3000), (40000, 2), (4096, 4097),
+                                  (59800, 2990), (65536, 30000), (70001, 30000), (100000, 30000), (5000, 2 ** 31 - 1), (66000, 2 ** 24 + 5)])
+def test_rank_metrics_device_vs_numpy(n, hi):
     from laff_amd import ops
-    g = rnd(n)
-    r = g.integers(1, 3000, n).astype(np.int32)
-    r[: n // 3] = 1
+    g = rnd(n + hi % 1000)
+    r = g.integers(1, hi, n).astype(np.int32)
+    if hi > 2:
+        r[: n // 3] = 1
     got = ops.rank_metrics(dev(r, torch.int32))
     ranks = r.astype(np.float64)
     exp = (100.0 * np.mean(ranks <= 1), 100.0 * np.mean(ranks <= 5), 100.0 * np.mean(ranks <= 10), np.floor(np.median(ranks)),
