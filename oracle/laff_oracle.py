@@ -297,3 +297,39 @@ FRAME_ATTENTION_FLAGS = {  # model/model.py:94-97 (name -> with_ave, mul)
     'average_AverageMul_noAve': (False, True),
 }
 
+
+
+# ---- text-side feature producers ---------------------------------------------------------
+def tokenize(text, clean=True, remove_stopword=False, stopwords=()):
+    """textlib.TextTool.tokenize, English branch (textlib.py:27-45): CR -> space, every non [A-Za-z0-9] -> space,
+    strip, lower, whitespace split; optional stop-word removal."""
+    import re
+    sent = text
+    if clean:
+        sent = sent.replace('\r', ' ')
+        sent = re.sub(r"[^A-Za-z0-9]", " ", sent).strip().lower()
+    tokens = sent.split()
+    if remove_stopword:
+        tokens = [t for t in tokens if t not in stopwords]
+    return tokens
+
+
+def bow_encoding(text, vocab, remove_stopword=False, stopwords=()):
+    """txt2vec.BowVec._encoding / BowVecNSW (txt2vec.py:56-63, :135-142): count vector over the vocabulary, norm=0."""
+    index = {w: i for i, w in enumerate(vocab)}
+    vec = np.zeros(len(vocab))
+    for w in tokenize(text, True, remove_stopword, stopwords):
+        i = index.get(w, -1)
+        if i >= 0:
+            vec[i] += 1
+    return vec
+
+
+def w2v_encoding(text, words, table, remove_stopword=False, stopwords=()):
+    """txt2vec.W2Vec._encoding / W2VecNSW (txt2vec.py:97-104, :145-149): BigFile.read dedups the tokens and drops the
+    unknown ones (bigfile.py:187-213), then the vectors are averaged; zeros if none is known."""
+    index = {w: i for i, w in enumerate(words)}
+    rows = sorted({index[w] for w in tokenize(text, True, remove_stopword, stopwords) if w in index})
+    if not rows:
+        return np.zeros(table.shape[1])
+    return np.array([table[r].tolist() for r in rows]).mean(axis=0)

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import laff_oracle as O
 from laff_amd.config import make_config
 from laff_amd.model import get_model
 from util import load_sd, maxdiff
@@ -180,3 +181,34 @@ def test_laff_towers_golden_fp16x3_fc(golden):
             assert maxdiff(te, g[k + '/txt_emb']) <= 5e-6
     finally:
         M.FC_PRECISION = 'fp32'
+
+
+def test_text_feature_producers_on_device_match_reference_fixture(golden):
+    """bow: captions -> CSR -> gather-sum FC == the reference's dense count vector through nn.Linear; w2v: mean-pool."""
+    import json
+    from laff_amd import txt2vec as T
+    from laff_amd.model.model import TransformNet
+    z = golden('txt2vec')
+    caps = json.loads(str(z['captions']))
+    stop = set(json.loads(str(z['stopwords'])))
+    vocab = json.loads(str(z['vocab']))
+    words = json.loads(str(z['w2v_words']))
+    w2v = T.W2Vec(words, z['w2v_table'], stop)
+    got = T.W2VTxtEncoder(w2v, DEV)({'caption': caps})['text_features']
+    assert got.shape == (len(caps), 20)
+    assert np.abs(got.cpu().numpy() - z['w2v_nsw']).max() <= 1e-6
+    bow = T.BowVec(vocab, stop)
+    enc = T.BoWTxtEncoder(bow, DEV)
+    x = enc({'caption': caps})['text_features']
+    assert x.layout == torch.sparse_csr
+    torch.manual_seed(5)
+    import laff_amd.model.model as M
+    M.device = torch.device(DEV)
+    net = TransformNet((len(vocab), 64), None, None, True, 'tanh').to(DEV).eval()
+    net.bn1.running_mean.normal_(0, 0.1)
+    net.bn1.running_var.uniform_(0.5, 1.5)
+    y = net(x)
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    ref = O.transform_net(z['bow_nsw'].astype(np.float32), sd['fc1.weight'], sd['fc1.bias'], 'tanh',
+                          O._bn_from_sd(sd, ''))
+    assert np.abs(y.cpu().numpy() - ref).max() <= 1e-5

@@ -133,3 +133,52 @@ def test_spec_workload_features_and_csr_row_shards():
     parts = [synth.slice_rows(bow, lo, hi).to_dense() for lo, hi in ((0, 1), (1, 250), (250, 600))]
     assert torch.equal(torch.cat(parts), dense)
     assert torch.equal(synth.slice_rows(vis['x3d'], 3, 9), vis['x3d'][3:9])
+
+
+def test_txt2vec_host_side_matches_reference_fixture():
+    """laff_amd.txt2vec: tokenisation, id mapping and CSR construction (host logic; the gather-sum itself is a GPU test)."""
+    import json
+    import os
+    import pickle
+    import tempfile
+    import torch
+    from laff_amd import txt2vec as T
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'txt2vec.npz'))
+    caps = json.loads(str(z['captions']))
+    stop = set(json.loads(str(z['stopwords'])))
+    vocab = json.loads(str(z['vocab']))
+    assert [T.tokenize(c) for c in caps] == json.loads(str(z['tokens_all']))
+    assert [T.tokenize(c, True, True, stop) for c in caps] == json.loads(str(z['tokens_nsw']))
+    for key, sw in (('bow', None), ('bow_nsw', stop)):
+        t2v = T.BowVec(vocab, sw)
+        assert t2v.ndims == len(vocab) == len(t2v)
+        assert np.array_equal(np.stack([t2v.encoding(c) for c in caps]), z[key])
+        csr = t2v.csr(caps, torch.device('cpu'))
+        assert csr.layout == torch.sparse_csr and csr.crow_indices().dtype == torch.int32
+        assert np.array_equal(csr.to_dense().numpy(), z[key].astype(np.float32))
+    words = json.loads(str(z['w2v_words']))
+    for key, sw in (('w2v', None), ('w2v_nsw', stop)):
+        t2v = T.W2Vec(words, z['w2v_table'], sw)
+        assert np.allclose(np.stack([t2v.encoding(c) for c in caps]), z[key], rtol=0, atol=1e-15)
+        dense = t2v.csr(caps, torch.device('cpu')).to_dense().numpy().astype(np.float64) @ z['w2v_table'].astype(np.float64)
+        assert np.abs(dense - z[key]).max() <= 1e-6
+    # a vocabulary pickled under a module that is not importable here (the reference pickles textlib.Vocabulary) loads into ours
+    import sys
+    import types
+    mod = types.ModuleType('textlib_standin')
+
+    class Vocabulary(object):
+        pass
+    Vocabulary.__module__, Vocabulary.__qualname__ = 'textlib_standin', 'Vocabulary'
+    mod.Vocabulary = Vocabulary
+    sys.modules['textlib_standin'] = mod
+    v = Vocabulary()
+    v.word2idx = {w: i for i, w in enumerate(vocab)}
+    v.idx2word = {i: w for i, w in enumerate(vocab)}
+    v.encoding = 'bow'
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, 'bow_nsw_5.pkl')
+        pickle.dump(v, open(path, 'wb'))
+        del sys.modules['textlib_standin']
+        t2v = T.BowVec(path, stop)
+        assert isinstance(t2v.vocab, T.Vocabulary) and t2v.vocab.find(vocab[3]) == 3 and t2v.ndims == len(vocab)

@@ -187,3 +187,23 @@ def test_bigfile_fixture_is_wellformed():
     for name, e in exp.items():
         mat = np.fromfile(os.path.join(GOLDEN, name, 'feature.bin'), dtype=np.float32).reshape(e['shape'])
         np.testing.assert_array_equal(mat, np.array(e['matrix'], np.float32))
+
+
+def test_txt2vec_oracle_matches_reference_encoders(golden):
+    """tokenizer + bow count vectors + w2v mean-pool against txt2vec.BowVec(NSW) / W2Vec(NSW) outputs of the reference."""
+    import json
+    z = golden('txt2vec')
+    caps = json.loads(str(z['captions']))
+    stop = set(json.loads(str(z['stopwords'])))
+    vocab = json.loads(str(z['vocab']))
+    words = json.loads(str(z['w2v_words']))
+    table = z['w2v_table']
+    assert [O.tokenize(c) for c in caps] == json.loads(str(z['tokens_all']))
+    assert [O.tokenize(c, True, True, stop) for c in caps] == json.loads(str(z['tokens_nsw']))
+    assert [O.tokenize(c, clean=False) for c in caps] == json.loads(str(z['tokens_noclean']))
+    for key, rm in (('bow', False), ('bow_nsw', True)):
+        got = np.stack([O.bow_encoding(c, vocab, rm, stop) for c in caps])
+        assert np.array_equal(got, z[key])
+    for key, rm in (('w2v', False), ('w2v_nsw', True)):
+        got = np.stack([O.w2v_encoding(c, words, table, rm, stop) for c in caps])
+        assert np.array_equal(got, z[key])

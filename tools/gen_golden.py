@@ -727,7 +727,59 @@ def gen_writers():
     save('writers', **arrays)
 
 
+# ----------------------------------------------------------------------------------------------
+# (12) text-side feature producers: txt2vec.BowVec(NSW) / W2Vec(NSW) + textlib.TextTool.tokenize
+# ----------------------------------------------------------------------------------------------
+def gen_txt2vec():
+    import pickle
+    import tempfile
+    import textlib as ref_textlib
+    import txt2vec as ref_t2v
+    g = rng(1212)
+    stop = sorted(ref_textlib.ENGLISH_STOP_WORDS)
+    content = ['man', 'woman', 'girl', 'young', 'two', 'dog', 'cat', 'car', 'street', 'guitar', 'playing', 'singing', 'dancing',
+               'kitchen', 'cooking', 'food', 'talking', 'camera', 'stage', 'crowd', 'game', 'soccer', 'player', 'ball', 'running',
+               'water', 'beach', 'baby', 'laughing', 'video', '2', '3d', 'tv', 'news', 'anchor', 'cartoon', 'character', 'minecraft']
+    vocab_words = content[:30] + ['the', 'a', 'is', 'on']        # a vocabulary WITH a few stop words (the non-NSW flavour)
+    captions = ['A man is playing the guitar on a stage.', 'Two young girls dancing & singing!!', 'a dog, a DOG and a cat',
+                'minecraft gameplay video', '', 'the a is on', "someone's cooking food in the kitchen\r\nwhile talking",
+                'UNKNOWNWORD zzz', 'man man man woman', 'Soccer-player kicks ball; crowd laughing 3D tv 2', '  water   beach  ',
+                'a cartoon character is talking to the camera', 'news anchor', 'baby']
+    arrays = {'captions': np.array(json.dumps(captions)), 'stopwords': np.array(json.dumps(stop)),
+              'vocab': np.array(json.dumps(vocab_words))}
+    for rm in (False, True):
+        arrays['tokens_%s' % ('nsw' if rm else 'all')] = np.array(json.dumps(
+            [ref_textlib.TextTool.tokenize(c, clean=True, language='en', remove_stopword=rm) for c in captions]))
+    arrays['tokens_noclean'] = np.array(json.dumps([ref_textlib.TextTool.tokenize(c, clean=False) for c in captions]))
+    with tempfile.TemporaryDirectory() as d:
+        voc = ref_textlib.Vocabulary('bow')
+        for w in vocab_words:
+            voc.add(w)
+        for fname, cls, key in (('bow_5.pkl', ref_t2v.BowVec, 'bow'), ('bow_nsw_5.pkl', ref_t2v.BowVecNSW, 'bow_nsw')):
+            path = os.path.join(d, fname)
+            pickle.dump(voc, open(path, 'wb'))
+            t2v = cls(path)
+            arrays[key] = np.stack([t2v.encoding(c) for c in captions])          # float64 count vectors
+            assert t2v.ndims == len(vocab_words)
+        # word2vec table as a BigFile directory
+        w2v_words = content[5:38] + ['the', 'on']
+        ndims = 20
+        table = f32(g.normal(0, 1, (len(w2v_words), ndims)))
+        wdir = os.path.join(d, 'vec20')
+        os.makedirs(wdir)
+        table.tofile(os.path.join(wdir, 'feature.bin'))
+        open(os.path.join(wdir, 'id.txt'), 'w').write(' '.join(w2v_words))
+        open(os.path.join(wdir, 'shape.txt'), 'w').write('%d %d' % table.shape)
+        for cls, key in ((ref_t2v.W2Vec, 'w2v'), (ref_t2v.W2VecNSW, 'w2v_nsw')):
+            t2v = cls(wdir)
+            arrays[key] = np.stack([t2v.encoding(c) for c in captions])          # float64 means
+        arrays['w2v_words'] = np.array(json.dumps(w2v_words))
+        arrays['w2v_table'] = table
+    save('txt2vec', **arrays)
+
+
 GENERATORS = {
+    'txt2vec': gen_txt2vec,
     'attention_1': gen_attention_1, 'multi_head': gen_multi_head, 'transform_net': gen_transform_net,
     'laff_towers': gen_laff_towers, 'framelaff': gen_framelaff, 'txt2vis': gen_txt2vis,
     'predict': gen_predict, 'eval': gen_eval, 'bigfile': gen_bigfile, 'writers': gen_writers,
