@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 3
+#define LAFF_ABI_VERSION 4
 
 enum {
     LAFF_OK = 0,
@@ -112,6 +112,17 @@ int laff_fc_act_bn_split_grouped(laff_ctx* ctx, const laff_fc_split_problem* pro
 int laff_fc_gather_act_bn(laff_ctx* ctx, const int* indptr, const int* indices, const float* values, int N, int Dk,
                           const float* Wt, int ldwt, const float* bias, const float* bn_scale, const float* bn_shift, int D,
                           int act, float* Y, int ldy);
+
+/* ---- 8f-4: training loss -- MarginRankingLoss (loss.py:68-135) per head, summed over heads (model/model.py:2032-2048) ----
+ * s = caption embeddings, im = video embeddings, both [B, H, d] fp32 contiguous (H = 1 for a 2-D batch).
+ * scores_h = l2norm(im_h) . l2norm(s_h)^T (eps 1e-13, loss.py:30-34); hinge on the margin against the diagonal, row-wise
+ * ('i2t'), column-wise ('t2i') or both; max_violation keeps the hardest negative; cost_style sum or mean.
+ * Writes loss[0] (device float) and, when non-NULL, the gradients d_s / d_im [B, H, d] of that loss (what autograd gives the
+ * reference).  workspace: caller-owned device scratch of laff_margin_loss_workspace_bytes(B, H, d), 16-byte aligned. */
+enum { LAFF_LOSS_MAX_VIOLATION = 1, LAFF_LOSS_COST_MEAN = 2, LAFF_LOSS_DIR_I2T = 4, LAFF_LOSS_DIR_T2I = 8 };
+int laff_margin_loss_workspace_bytes(int B, int H, int d, size_t* out);
+int laff_margin_loss(laff_ctx* ctx, const float* s, const float* im, int B, int H, int d, float margin, unsigned flags,
+                     float* loss, float* d_s, float* d_im, void* workspace, size_t workspace_bytes);
 
 /* ---- a2-a6: stack + Multi_head_MyApply_Attention / Attention_1 / JustAverage ----------------------------
  * (model/model.py:1858-1876, :1663-1705; model/Attention.py:508-531, :78-105)

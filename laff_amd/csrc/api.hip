@@ -181,6 +181,79 @@ int laff_fc_gather_act_bn(laff_ctx* ctx, const int* indptr, const int* indices, 
     return LAFF_OK;
 }
 
+namespace {
+struct LossLayout {
+    size_t XH, XHT, nrm, npr, S, dS, dST, G, loss_h, total;   // offsets in floats
+    int dp, Bp;
+};
+LossLayout loss_layout(int B, int H, int d) {
+    LossLayout L{};
+    L.dp = (d + 3) & ~3;
+    L.Bp = (B + 3) & ~3;
+    auto up4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+    size_t o = 0;
+    L.XH = o;     o += up4((size_t)2 * H * B * L.dp);
+    L.XHT = o;    o += up4((size_t)2 * H * d * L.Bp);
+    L.nrm = o;    o += up4((size_t)2 * H * B);
+    L.npr = o;    o += up4((size_t)2 * H * B);
+    L.S = o;      o += up4((size_t)H * B * L.Bp);
+    L.dS = o;     o += up4((size_t)H * B * L.Bp);
+    L.dST = o;    o += up4((size_t)H * B * L.Bp);
+    L.G = o;      o += up4((size_t)2 * H * B * L.dp);
+    L.loss_h = o; o += up4((size_t)H);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+int laff_margin_loss_workspace_bytes(int B, int H, int d, size_t* out) {
+    if (!out || B < 1 || H < 1 || d < 1) return fail(LAFF_E_ARG, "laff_margin_loss_workspace_bytes: bad args");
+    *out = loss_layout(B, H, d).total * sizeof(float);
+    return LAFF_OK;
+}
+
+int laff_margin_loss(laff_ctx* ctx, const float* s, const float* im, int B, int H, int d, float margin, unsigned flags,
+                     float* loss, float* d_s, float* d_im, void* workspace, size_t workspace_bytes) {
+    CHECK_CTX(ctx);
+    if (!s || !im || !loss || !workspace) return fail(LAFF_E_ARG, "laff_margin_loss: null argument");
+    if (B < 1 || H < 1 || d < 1 || B > 16384) return fail(LAFF_E_SHAPE, "laff_margin_loss: bad shape B=%d H=%d d=%d", B, H, d);
+    if (flags & ~15u) return fail(LAFF_E_ARG, "laff_margin_loss: unknown flags 0x%x", flags);
+    const LossLayout L = loss_layout(B, H, d);
+    if (workspace_bytes < L.total * sizeof(float)) return fail(LAFF_E_ARG, "laff_margin_loss: workspace too small (%zu < %zu bytes)", workspace_bytes, L.total * sizeof(float));
+    if (!aligned16(workspace)) return fail(LAFF_E_ALIGN, "laff_margin_loss: workspace must be 16-byte aligned");
+    if ((size_t)(2 * B + 16) * sizeof(float) > 64 * 1024) return fail(LAFF_E_UNSUPPORTED, "laff_margin_loss: B=%d exceeds the reduction kernel's LDS budget", B);
+    DeviceGuard g(ctx->device);
+    float* ws = (float*)workspace;
+    const int dp = L.dp, Bp = L.Bp;
+    const int use_s = (flags & LAFF_LOSS_DIR_I2T) ? 1 : 0, use_im = (flags & LAFF_LOSS_DIR_T2I) ? 1 : 0;
+    const int maxv = (flags & LAFF_LOSS_MAX_VIOLATION) ? 1 : 0;
+    const float gmean = maxv ? 1.0f / (float)B : 1.0f / ((float)B * (float)B);
+    const float gw = (flags & LAFF_LOSS_COST_MEAN) ? gmean : 1.0f;
+    HIP_TRY(laff::launch_loss_normalize(s, im, B, H, d, dp, Bp, 1e-13f, ws + L.XH, ws + L.XHT, ws + L.nrm, ws + L.npr, ctx->stream));
+    auto XH = [&](int z, int h) { return ws + L.XH + ((size_t)z * H + h) * B * dp; };
+    auto XHT = [&](int z, int h) { return ws + L.XHT + ((size_t)z * H + h) * d * Bp; };
+    auto G = [&](int z, int h) { return ws + L.G + ((size_t)z * H + h) * B * dp; };
+    std::vector<laff_fc_problem> probs((size_t)H);
+    for (int h = 0; h < H; ++h)      // scores_h [B videos, B captions] = I^_h . S^_h^T
+        probs[h] = laff_fc_problem{XH(1, h), B, d, dp, XH(0, h), dp, nullptr, nullptr, nullptr, B, LAFF_ACT_NONE,
+                                   ws + L.S + (size_t)h * B * Bp, Bp};
+    if (int rc = laff_fc_act_bn_grouped(ctx, probs.data(), H)) return rc;
+    HIP_TRY(laff::launch_margin_reduce(ws + L.S, ws + L.dS, ws + L.dST, ws + L.loss_h, loss, B, Bp, H, margin, maxv, use_s, use_im,
+                                       gw, gw, ctx->stream));
+    if (!d_s && !d_im) return LAFF_OK;
+    probs.clear();
+    for (int h = 0; h < H; ++h) {
+        // dL/dI^_h = dS_h . S^_h   (column operand = S^_h^T, K = captions);  dL/dS^_h = dS_h^T . I^_h
+        probs.push_back(laff_fc_problem{ws + L.dS + (size_t)h * B * Bp, B, B, Bp, XHT(0, h), Bp, nullptr, nullptr, nullptr, d,
+                                        LAFF_ACT_NONE, G(1, h), dp});
+        probs.push_back(laff_fc_problem{ws + L.dST + (size_t)h * B * Bp, B, B, Bp, XHT(1, h), Bp, nullptr, nullptr, nullptr, d,
+                                        LAFF_ACT_NONE, G(0, h), dp});
+    }
+    if (int rc = laff_fc_act_bn_grouped(ctx, probs.data(), (int)probs.size())) return rc;
+    HIP_TRY(laff::launch_loss_normalize_bwd(ws + L.XH, ws + L.G, ws + L.nrm, ws + L.npr, B, H, d, dp, d_s, d_im, ctx->stream));
+    return LAFF_OK;
+}
+
 int laff_split_rows_bytes(int N, int K, size_t* out) {
     if (!out || N < 0 || K < 1) return fail(LAFF_E_ARG, "laff_split_rows_bytes: bad args");
     const size_t Kp = (size_t)(K + 63) / 64 * 64;

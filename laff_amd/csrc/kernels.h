@@ -83,6 +83,12 @@ hipError_t launch_frame_fuse(const FrameArgs& a, hipStream_t st);
 hipError_t launch_split_rows_grouped(int count, const float* const* X, const int* N, const int* K, const int* ldx, void* const* out,
                                      float* const* rscale, hipStream_t st);
 hipError_t launch_split_rows(const float* X, int N, int K, int ldx, int Kp, void* out, float* rscale, hipStream_t st);
+hipError_t launch_loss_normalize(const float* s, const float* im, int B, int H, int d, int dp, int Bp, float eps, float* XH,
+                                 float* XHT, float* nrm, float* npr, hipStream_t st);
+hipError_t launch_margin_reduce(const float* S, float* dS, float* dST, float* loss_h, float* loss, int B, int Bp, int H,
+                                float margin, int max_violation, int use_s, int use_im, float g_s, float g_im, hipStream_t st);
+hipError_t launch_loss_normalize_bwd(const float* XH, const float* G, const float* nrm, const float* npr, int B, int H, int d,
+                                     int dp, float* d_s, float* d_im, hipStream_t st);
 hipError_t launch_fc_gather(const int* indptr, const int* indices, const float* values, int N, int Dk, const float* Wt, int ldwt,
                             const float* bias, const float* bn_scale, const float* bn_shift, int D, int act, float* Y, int ldy,
                             hipStream_t st);

@@ -580,10 +580,11 @@ class W2VVPP_MutiVis(W2VVPP):
         self.vis_net = VisMutiTransformNetAddAttnetion(opt, opt.vis_fc_layers[0])
 
     def change_raw_global_emb_weight(self):
-        """Linear decay of gw, once per epoch in the reference (model/model.py:1910-1941)."""
+        """Linear decay of gw, once per epoch in the reference (model/model.py:1910-1941).  Like the reference it only looks
+        for an attribute called `attention_layer`: the FrameLAFF video tower (`vis_attention_layer`) is never decayed."""
         for net, rate in ((self.txt_net, self.opt.txt_attention_global_decay_rate),
                           (self.vis_net, self.opt.vis_attention_global_decay_rate)):
-            layer = getattr(net, 'attention_layer', None) or getattr(net, 'vis_attention_layer', None)
+            layer = getattr(net, 'attention_layer', None)
             if layer is not None and hasattr(layer, 'get_raw_global_emb_weight'):
                 layer.change_raw_global_emb_weight(max(0.0, rate - 1 + layer.get_raw_global_emb_weight()))
 

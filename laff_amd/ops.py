@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, FcSplitProblem, Plane, check)
 
-__all__ = ['topk_rows', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['topk_rows', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -146,6 +146,37 @@ def fc_gather_act_bn(x_csr, weight_t, bias=None, bn_scale=None, bn_shift=None, a
     _call('fc_gather', lib.laff_fc_gather_act_bn, h, _ptr(crow), _ptr(col), _ptr(val), N, Dk, _ptr(wt), ldwt, _ptr(bias),
           _ptr(bn_scale), _ptr(bn_shift), D, ACT[activation], _ptr(out), D)
     return out
+
+
+LOSS_FLAGS = {'max_violation': 1, 'mean': 2, 'i2t': 4, 't2i': 8}
+
+
+def margin_loss(s, im, margin, max_violation=True, cost_style='sum', direction='t2i', want_grad=True):
+    """MarginRankingLoss over heads (laff_margin_loss).  s, im: (B, d) or (B, H, d) fp32 CUDA tensors.
+    Returns (loss 0-d tensor, d_s, d_im) -- the gradients are None when want_grad is False."""
+    if s.shape != im.shape or s.dim() not in (2, 3):
+        raise ValueError('s and im must both be (B, d) or (B, H, d); got %s and %s' % (tuple(s.shape), tuple(im.shape)))
+    if direction not in ('i2t', 't2i', 'bidir'):
+        raise ValueError("direction must be 'i2t', 't2i' or 'bidir'")
+    if cost_style not in ('sum', 'mean'):
+        raise ValueError("cost_style must be 'sum' or 'mean'")
+    s_c = _dev(s.contiguous(), 's')
+    im_c = _dev(im.contiguous(), 'im')
+    B, H, d = (s.shape[0], 1, s.shape[1]) if s.dim() == 2 else s.shape
+    flags = (LOSS_FLAGS['max_violation'] if max_violation else 0) | (LOSS_FLAGS['mean'] if cost_style == 'mean' else 0)
+    flags |= {'i2t': LOSS_FLAGS['i2t'], 't2i': LOSS_FLAGS['t2i'], 'bidir': LOSS_FLAGS['i2t'] | LOSS_FLAGS['t2i']}[direction]
+    lib, h = _context(s_c.device)
+    nbytes = C.c_size_t()
+    rc = lib.laff_margin_loss_workspace_bytes(B, H, d, C.byref(nbytes))
+    if rc:
+        raise RuntimeError(lib.laff_last_error().decode())
+    ws = torch.empty(nbytes.value, dtype=torch.uint8, device=s_c.device)
+    loss = torch.empty((), dtype=torch.float32, device=s_c.device)
+    d_s = torch.empty_like(s_c) if want_grad else None
+    d_im = torch.empty_like(im_c) if want_grad else None
+    _call('margin_loss', lib.laff_margin_loss, h, _ptr(s_c), _ptr(im_c), B, H, d, float(margin), flags, _ptr(loss), _ptr(d_s),
+          _ptr(d_im), _ptr(ws), nbytes.value)
+    return loss, d_s, d_im
 
 
 class SplitOperand:

@@ -333,3 +333,74 @@ def w2v_encoding(text, words, table, remove_stopword=False, stopwords=()):
     if not rows:
         return np.zeros(table.shape[1])
     return np.array([table[r].tolist() for r in rows]).mean(axis=0)
+
+
+# ---- training loss ------------------------------------------------------------------------
+def margin_ranking_loss(s, im, margin=0.2, max_violation=True, cost_style='sum', direction='t2i'):
+    """loss.MarginRankingLoss.forward (loss.py:99-135) with measure='cosine', summed over heads like
+    model/model.py:2037-2039, plus the gradients autograd gives the reference (restated analytically).
+
+    s (captions), im (videos): (B, d) or (B, H, d).  Returns (loss float32, d_s, d_im)."""
+    s = _f32(s)
+    im = _f32(im)
+    squeeze = s.ndim == 2
+    if squeeze:
+        s, im = s[:, None, :], im[:, None, :]
+    B, H, d = s.shape
+    total = F32(0.0)
+    d_s = np.zeros_like(s)
+    d_im = np.zeros_like(im)
+    eye = np.eye(B, dtype=bool)
+    for h in range(H):
+        xs, xi = s[:, h, :], im[:, h, :]
+        rs = np.sqrt((xs * xs).sum(1, keepdims=True)).astype(F32)
+        ri = np.sqrt((xi * xi).sum(1, keepdims=True)).astype(F32)
+        ns = rs + F32(1e-13) + F32(1e-14)
+        ni = ri + F32(1e-13) + F32(1e-14)
+        hs, hi = (xs / ns).astype(F32), (xi / ni).astype(F32)
+        scores = (hi @ hs.T).astype(F32)                               # self.sim(im, s): rows = videos (loss.py:102)
+        diag = np.diag(scores).copy()
+        dS = np.zeros((B, B), F32)
+        loss_h = F32(0.0)
+        if direction in ('i2t', 'bidir'):
+            cost = np.maximum(F32(margin) + scores - diag[:, None], F32(0)).astype(F32)
+            cost[eye] = 0
+            if max_violation:
+                j = cost.argmax(1)
+                v = cost[np.arange(B), j]
+                w = F32(1.0 / B) if cost_style == 'mean' else F32(1)
+                loss_h += (v.sum() * w) if cost_style == 'sum' else v.mean()
+                act = v > 0
+                np.add.at(dS, (np.arange(B)[act], j[act]), w)
+                np.add.at(dS, (np.arange(B)[act], np.arange(B)[act]), -w)
+            else:
+                w = F32(1.0 / (B * B)) if cost_style == 'mean' else F32(1)
+                loss_h += cost.sum() if cost_style == 'sum' else cost.mean()
+                act = cost > 0
+                dS += act * w
+                dS[np.arange(B), np.arange(B)] -= act.sum(1) * w
+        if direction in ('t2i', 'bidir'):
+            cost = np.maximum(F32(margin) + scores - diag[None, :], F32(0)).astype(F32)
+            cost[eye] = 0
+            if max_violation:
+                i = cost.argmax(0)
+                v = cost[i, np.arange(B)]
+                w = F32(1.0 / B) if cost_style == 'mean' else F32(1)
+                loss_h += (v.sum() * w) if cost_style == 'sum' else v.mean()
+                act = v > 0
+                np.add.at(dS, (i[act], np.arange(B)[act]), w)
+                np.add.at(dS, (np.arange(B)[act], np.arange(B)[act]), -w)
+            else:
+                w = F32(1.0 / (B * B)) if cost_style == 'mean' else F32(1)
+                loss_h += cost.sum() if cost_style == 'sum' else cost.mean()
+                act = cost > 0
+                dS += act * w
+                dS[np.arange(B), np.arange(B)] -= act.sum(0) * w
+        total = F32(total + F32(loss_h))
+        g_hi = dS @ hs                                                   # d loss / d normalised videos
+        g_hs = dS.T @ hi
+        d_im[:, h, :] = g_hi / ni - hi * ((hi * g_hi).sum(1, keepdims=True) / ri)
+        d_s[:, h, :] = g_hs / ns - hs * ((hs * g_hs).sum(1, keepdims=True) / rs)
+    if squeeze:
+        d_s, d_im = d_s[:, 0, :], d_im[:, 0, :]
+    return F32(total), d_s.astype(F32), d_im.astype(F32)

@@ -466,3 +466,57 @@ def test_fc_gather_ignores_out_of_vocabulary_ids_and_rejects_bad_shapes():
         ops.fc_gather_act_bn(x, dev(W.T[:30]))
     with pytest.raises(RuntimeError):
         ops.fc_gather_act_bn(dev(np.zeros((3, Dk), np.float32)), dev(W.T))
+
+
+# ---------------------------------------------------------------------------------------------- 8f-4 training loss
+def test_margin_loss_golden_forward_and_backward(golden):
+    """laff_margin_loss against loss.MarginRankingLoss + autograd of the reference (per head, summed)."""
+    from laff_amd import ops
+    g = golden('margin_loss')
+    for c in g.json('cases'):
+        k = c['key']
+        loss, d_s, d_im = ops.margin_loss(dev(g[k + '/s']), dev(g[k + '/im']), c['margin'], c['max_violation'], c['cost_style'],
+                                          c['direction'])
+        ref = float(g[k + '/loss'])
+        assert abs(loss.item() - ref) <= 2e-5 * max(1.0, abs(ref)), c
+        assert maxdiff(d_s, g[k + '/d_s']) <= 2e-6, c
+        assert maxdiff(d_im, g[k + '/d_im']) <= 2e-6, c
+
+
+@pytest.mark.parametrize('B,H,d', [(128, 8, 512), (256, 1, 512), (1, 1, 8), (2, 3, 5), (130, 2, 30), (512, 4, 64)])
+@pytest.mark.parametrize('maxv,style,direction', [(True, 'sum', 't2i'), (False, 'sum', 'bidir'), (True, 'mean', 'bidir'), (False, 'mean', 'i2t')])
+def test_margin_loss_vs_oracle(B, H, d, maxv, style, direction):
+    from laff_amd import ops
+    g = rnd(B + H + d)
+    z = g.normal(0, 1, (B, 16)).astype(np.float32)
+    P = g.normal(0, 1, (16, H * d)).astype(np.float32)
+    s = (z @ P + 2.0 * g.normal(0, 1, (B, H * d))).astype(np.float32).reshape(B, H, d)
+    im = (z @ P + 2.0 * g.normal(0, 1, (B, H * d))).astype(np.float32).reshape(B, H, d)
+    loss, d_s, d_im = ops.margin_loss(dev(s), dev(im), 0.2, maxv, style, direction)
+    rl, rs, ri = O.margin_ranking_loss(s, im, 0.2, maxv, style, direction)
+    assert abs(loss.item() - float(rl)) <= 5e-5 * max(1.0, abs(float(rl)))
+    # a hinge / arg-max decision that flips on a 1-ulp score difference moves whole rows of the gradient: compare robustly
+    bad_s = (np.abs(d_s.cpu().numpy() - rs).max(axis=-1) > 5e-6).mean()
+    bad_i = (np.abs(d_im.cpu().numpy() - ri).max(axis=-1) > 5e-6).mean()
+    assert bad_s <= 0.01 and bad_i <= 0.01, (bad_s, bad_i)
+    # forward-only call leaves no gradient buffers
+    l2, a, b = ops.margin_loss(dev(s), dev(im), 0.2, maxv, style, direction, want_grad=False)
+    assert a is None and b is None and abs(l2.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
+
+
+def test_margin_loss_module_plugs_into_autograd_and_2d_inputs():
+    from laff_amd import loss as L
+    g = rnd(77)
+    s = torch.tensor(g.normal(0, 1, (40, 64)).astype(np.float32), device=DEV, requires_grad=True)
+    im = torch.tensor(g.normal(0, 1, (40, 64)).astype(np.float32), device=DEV, requires_grad=True)
+    crit = L.MarginRankingLoss(margin=0.2, max_violation=True, cost_style='sum', direction='t2i')
+    loss, items = L.compute_loss(crit, im, s)
+    (3.0 * loss).backward()
+    rl, rs, ri = O.margin_ranking_loss(s.detach().cpu().numpy(), im.detach().cpu().numpy(), 0.2, True, 'sum', 't2i')
+    assert abs(loss.item() - float(rl)) <= 2e-5 * max(1.0, float(rl)) and items['triplet_loss'] is loss
+    assert maxdiff(s.grad, 3.0 * rs) <= 1e-5 and maxdiff(im.grad, 3.0 * ri) <= 1e-5
+    with pytest.raises(NotImplementedError):
+        L.MarginRankingLoss(measure='hist')
+    with pytest.raises(ValueError):
+        from laff_amd import ops
+        ops.margin_loss(s.detach(), im.detach()[:, :32], 0.2)

@@ -182,3 +182,24 @@ def test_txt2vec_host_side_matches_reference_fixture():
         del sys.modules['textlib_standin']
         t2v = T.BowVec(path, stop)
         assert isinstance(t2v.vocab, T.Vocabulary) and t2v.vocab.find(vocab[3]) == 3 and t2v.ndims == len(vocab)
+
+
+def test_gw_linear_decay_per_epoch():
+    """W2VVPP_MutiVis.change_raw_global_emb_weight (model/model.py:1910-1941): gw <- max(0, gw + rate - 1) on both towers."""
+    import torch
+    from laff_amd.config import make_config
+    from laff_amd.model import get_model
+    cfg = make_config({'a': 8, 'b': 8}, {'bow': 8, 'w2v': 8}, 16, 2, 'LAFF', with_ave=True)
+    cfg.txt_attention_global_decay_rate, cfg.vis_attention_global_decay_rate = 0.8, 0.7
+    model = get_model('LAFF', torch.device('cpu'), cfg)
+    t, v = model.txt_net.attention_layer, model.vis_net.attention_layer
+    assert t.get_raw_global_emb_weight() == 1.0 and v.get_raw_global_emb_weight() == 1.0
+    seen = []
+    for _ in range(6):
+        model.change_raw_global_emb_weight()
+        seen.append((round(t.get_raw_global_emb_weight(), 6), round(v.get_raw_global_emb_weight(), 6)))
+    assert seen == [(0.8, 0.7), (0.6, 0.4), (0.4, 0.1), (0.2, 0.0), (0.0, 0.0), (0.0, 0.0)]
+    for layer in (t, v):                                      # every head carries the same value
+        sd = layer.state_dict()
+        vals = [float(x) for k, x in sd.items() if k.endswith('global_emb_weight_net.weight')]
+        assert len(vals) == 2 and len(set(vals)) == 1

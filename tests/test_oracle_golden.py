@@ -207,3 +207,15 @@ def test_txt2vec_oracle_matches_reference_encoders(golden):
     for key, rm in (('w2v', False), ('w2v_nsw', True)):
         got = np.stack([O.w2v_encoding(c, words, table, rm, stop) for c in caps])
         assert np.array_equal(got, z[key])
+
+
+def test_margin_ranking_loss_oracle_matches_reference_autograd(golden):
+    g = golden('margin_loss')
+    for c in g.json('cases'):
+        k = c['key']
+        loss, d_s, d_im = O.margin_ranking_loss(g[k + '/s'], g[k + '/im'], c['margin'], c['max_violation'], c['cost_style'],
+                                                c['direction'])
+        assert abs(float(loss) - float(g[k + '/loss'])) <= 2e-5 * max(1.0, abs(float(g[k + '/loss']))), c
+        assert np.abs(d_s - g[k + '/d_s']).max() <= 2e-6, c
+        assert np.abs(d_im - g[k + '/d_im']).max() <= 2e-6, c
+        assert float(g[k + '/loss']) > 0 and np.abs(g[k + '/d_s']).max() > 0      # the fixture exercises violations

@@ -778,7 +778,44 @@ def gen_txt2vec():
     save('txt2vec', **arrays)
 
 
+# ----------------------------------------------------------------------------------------------
+# (13) training loss: loss.MarginRankingLoss forward + autograd backward, per head and summed (model.py:2032-2048)
+# ----------------------------------------------------------------------------------------------
+def gen_margin_loss():
+    g = rng(1313)
+    arrays = {}
+    cases = []
+    torch.set_grad_enabled(True)
+    try:
+        for ci, (B, H, d, margin, maxv, style, direction) in enumerate([
+                (24, 1, 32, 0.2, True, 'sum', 't2i'), (24, 1, 32, 0.2, False, 'sum', 'bidir'), (37, 8, 64, 0.2, True, 'sum', 't2i'),
+                (37, 8, 64, 0.3, True, 'mean', 'bidir'), (50, 2, 48, 0.1, False, 'mean', 'i2t'), (33, 4, 20, 0.5, True, 'sum', 'i2t'),
+                (96, 8, 128, 0.2, True, 'sum', 't2i')]):
+            k = 'c%d' % ci
+            z = f32(g.normal(0, 1, (B, 16)))                       # shared latent: matched pairs score high, some violations
+            P = f32(g.normal(0, 1, (16, H * d)))
+            s = torch.tensor(f32(z @ P + 1.5 * g.normal(0, 1, (B, H * d))).reshape(B, H, d), requires_grad=True)
+            im = torch.tensor(f32(z @ P + 1.5 * g.normal(0, 1, (B, H * d))).reshape(B, H, d), requires_grad=True)
+            crit = ref_loss.MarginRankingLoss(margin=margin, measure='cosine', max_violation=maxv, cost_style=style,
+                                              direction=direction)
+            total = 0
+            for h in range(H):                                   # model/model.py:2037-2039
+                total = total + crit(s[:, h, :], im[:, h, :])
+            total.backward()
+            arrays[k + '/s'] = s.detach().numpy()
+            arrays[k + '/im'] = im.detach().numpy()
+            arrays[k + '/loss'] = np.float32(total.item())
+            arrays[k + '/d_s'] = s.grad.numpy()
+            arrays[k + '/d_im'] = im.grad.numpy()
+            cases.append(dict(key=k, B=B, H=H, d=d, margin=margin, max_violation=maxv, cost_style=style, direction=direction))
+    finally:
+        torch.set_grad_enabled(False)
+    arrays['cases'] = np.array(json.dumps(cases))
+    save('margin_loss', **arrays)
+
+
 GENERATORS = {
+    'margin_loss': gen_margin_loss,
     'txt2vec': gen_txt2vec,
     'attention_1': gen_attention_1, 'multi_head': gen_multi_head, 'transform_net': gen_transform_net,
     'laff_towers': gen_laff_towers, 'framelaff': gen_framelaff, 'txt2vis': gen_txt2vis,
