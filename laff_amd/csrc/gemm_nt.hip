@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "kernels.h"
 
 namespace laff {
@@ -48,8 +50,9 @@ struct Cfg {
     static constexpr int SMEM = 2 * STAGEB;
     static constexpr int ITR = TR * 8 / THREADS, ITC = TC * 8 / THREADS;   // 16-byte chunks per thread per stage
     static constexpr int WPS = (THREADS / 64) * ((160 * 1024) / SMEM) / 4;  // waves per SIMD the LDS budget admits
-    static_assert(WN == 2, "the epilogue slab assumes 64 output columns per wave");
-    static_assert(THREADS / 64 * 32 * 68 * 4 <= SMEM, "epilogue slabs must fit in the operand ring");
+    static constexpr int PITCH = WN * 32 + 4;                        // epilogue slab: 32 rows x (WN*32) fp32 per wave
+    static_assert(WN == 2 || WN == 4, "the epilogue store loop handles 64 or 128 output columns per wave");
+    static_assert(THREADS / 64 * 32 * PITCH * 4 <= SMEM, "epilogue slabs must fit in the operand ring");
 };
 using Cfg128 = Cfg<2, 2, 2, 2>;
 using Cfg256 = Cfg<4, 2, 2, 4>;
@@ -122,34 +125,18 @@ __device__ __forceinline__ uint4 lds_frag(const char* lds_op, int row, int chunk
 // ---- staging, fast path (STG 2: K bytes a multiple of the K-step, operand below 4 GiB): the per-lane part of every
 // source address is a 32-bit byte offset computed ONCE per tile; a K-step only advances a scalar base (saddr form), so
 // the main loop carries no address VALU.  LDS-DMA lands 16 B per lane at (wave-uniform M0 base) + lane*16.
-template <int IT>
-__device__ __forceinline__ void glds_issue(const unsigned (&off)[IT], unsigned long long sbase, unsigned dst0, unsigned stride) {
-    static_assert(IT == 2 || IT == 4, "");
+// one 1 KiB-per-wave piece of a stage (the K loop spreads a stage's pieces between MFMAs instead of issuing them in a burst)
+__device__ __forceinline__ void glds_piece(unsigned off, unsigned long long sbase, unsigned dst) {
     unsigned keep;
-    const unsigned d0 = __builtin_amdgcn_readfirstlane(dst0);
-    if constexpr (IT == 4) {
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-            "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-            "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
-            "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(sbase), "s"(d0), "s"(d0 + stride),
-              "s"(d0 + 2 * stride), "s"(d0 + 3 * stride)
-            : "memory");
-    } else {
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-            "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(off[0]), "v"(off[1]), "s"(sbase), "s"(d0), "s"(d0 + stride)
-            : "memory");
-    }
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(off), "s"(sbase), "s"(dst)
+        : "memory");
 }
+
 
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long x) {     // make wave-uniformity provable
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
@@ -175,7 +162,7 @@ enum { EPI_SIM = 0, EPI_FC = 1 };
 template <int EPI, bool FULL, typename CF>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM][CF::WN], int r0, int c0, int wr, int wc,
                                          int wave, int lane, char* smem) {
-    constexpr int WM = CF::WM, WN = CF::WN, PITCH = 68;
+    constexpr int WM = CF::WM, WN = CF::WN, PITCH = CF::PITCH;
     const int l31 = lane & 31, hh = lane >> 5;
     float* slab = (float*)smem + wave * (32 * PITCH);
     const int cw0 = c0 + wc * (WN * 32);               // first output column of this wave
@@ -255,11 +242,12 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
         }
         if (a.out) {
             __builtin_amdgcn_wave_barrier();
-            const int col4 = (lane & 15) * 4;
+            constexpr int LPR = WN * 8, RPI = 64 / LPR;      // lanes per slab row, rows per store instruction
+            const int col4 = (lane % LPR) * 4;
             const int gc = cw0 + col4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = (lane >> 4) + 4 * j;
+            for (int j = 0; j < 32 / RPI; ++j) {
+                const int row = lane / LPR + RPI * j;
                 const float4 v = *(const float4*)(slab + row * PITCH + col4);
                 const int gr = rbase + row;
                 float* o = a.out + (long)gr * a.ldo + gc;
@@ -357,8 +345,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
         const unsigned sa = lds0 + (unsigned)buf * CF::STAGEB;
         if constexpr (STG == 2) {
             const unsigned wbase = (unsigned)(tid & ~63) * 16u;
-            glds_issue<CF::ITR>(offR, uniform64(curR + (unsigned long long)kb0), sa + wbase, THREADS * 16u);
-            glds_issue<CF::ITC>(offC, uniform64(curC + (unsigned long long)kb0), sa + CF::OPB_R + wbase, THREADS * 16u);
+            const unsigned long long bR = uniform64(curR + (unsigned long long)kb0), bC = uniform64(curC + (unsigned long long)kb0);
+#pragma unroll
+            for (int it = 0; it < CF::ITR; ++it)
+                glds_piece(offR[it], bR, __builtin_amdgcn_readfirstlane(sa + wbase + it * (THREADS * 16u)));
+#pragma unroll
+            for (int it = 0; it < CF::ITC; ++it)
+                glds_piece(offC[it], bC, __builtin_amdgcn_readfirstlane(sa + CF::OPB_R + wbase + it * (THREADS * 16u)));
         } else {
             stage_operand<STG, CF::TR, THREADS>((const char*)curR, r0, a.nR, ldRb, kb0, Kb, s, sa, tid);
             stage_operand<STG, CF::TC, THREADS>((const char*)curC, c0, a.nC, ldCb, kb0, Kb, s + CF::OPB_R, sa + CF::OPB_R, tid);
@@ -391,6 +384,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
         constexpr int NR = WM + WN, NSUB = ROWB / 32;
         u32x4 fc[2][WN], fr[2][WM];
         auto issue = [&](int kt, int ks, int b) {
+#ifdef LAFF_ABL_NOREAD
+            if (kt | ks) return;                      // ablation: fragments are read once and reused (wrong results)
+#endif
             const unsigned stg_off = (unsigned)(kt & 1) * CF::STAGEB;
             const unsigned ar = laneR + stg_off + xk[ks], ac = laneC + stg_off + xk[ks];
 #pragma unroll
@@ -398,26 +394,57 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
 #pragma unroll
             for (int t = 0; t < WM; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[b][t]) : "v"(ar), "n"(t * 32 * ROWB));
         };
-        auto mfmas = [&](int b) {
-#pragma unroll
-            for (int tr = 0; tr < WM; ++tr)
-#pragma unroll
-                for (int tc = 0; tc < WN; ++tc) {
-                    if constexpr (MODE == GEMM_F32) {
-                        const f32x4 pa = __builtin_bit_cast(f32x4, fc[b][tc]), pb = __builtin_bit_cast(f32x4, fr[b][tr]);
-                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.x, pb.x, acc[tr][tc], 0, 0, 0);
-                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.y, pb.y, acc[tr][tc], 0, 0, 0);
-                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.z, pb.z, acc[tr][tc], 0, 0, 0);
-                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.w, pb.w, acc[tr][tc], 0, 0, 0);
-                    } else if constexpr (MODE == GEMM_F16) {
-                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            __builtin_bit_cast(f16x8, fc[b][tc]), __builtin_bit_cast(f16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
-                    } else {
-                        acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, fc[b][tc]), __builtin_bit_cast(bf16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
-                    }
-                }
+        // LDS-DMA of the stage being refilled, one piece at a time: pieces [0, ITR) are the row operand, the rest the
+        // column operand; `fillR/fillC/fill_sa` are the (wave-uniform) source bases and LDS slot of that stage.
+        constexpr int NPIECE = CF::ITR + CF::ITC;
+        constexpr int NP0 = (NPIECE + 2) / 3, NP1 = (NPIECE - NP0 + 1) / 2, NP2 = NPIECE - NP0 - NP1;
+        unsigned long long fillR = 0, fillC = 0;
+        unsigned fill_sa = 0;
+        bool fill_on = false;
+        const unsigned wbase = (unsigned)(tid & ~63) * 16u;
+        auto piece = [&](auto PC) {
+            constexpr int pc = decltype(PC)::value;
+            if constexpr (pc < CF::ITR)
+                glds_piece(offR[pc], fillR, __builtin_amdgcn_readfirstlane(fill_sa + wbase + pc * (THREADS * 16u)));
+            else
+                glds_piece(offC[pc - CF::ITR], fillC,
+                           __builtin_amdgcn_readfirstlane(fill_sa + CF::OPB_R + wbase + (pc - CF::ITR) * (THREADS * 16u)));
         };
+        auto mfma_one = [&](int b, auto TRC, auto TCC) {
+            constexpr int tr = decltype(TRC)::value, tc = decltype(TCC)::value;
+            if constexpr (MODE == GEMM_F32) {
+                const f32x4 pa = __builtin_bit_cast(f32x4, fc[b][tc]), pb = __builtin_bit_cast(f32x4, fr[b][tr]);
+                acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.x, pb.x, acc[tr][tc], 0, 0, 0);
+                acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.y, pb.y, acc[tr][tc], 0, 0, 0);
+                acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.z, pb.z, acc[tr][tc], 0, 0, 0);
+                acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.w, pb.w, acc[tr][tc], 0, 0, 0);
+            } else if constexpr (MODE == GEMM_F16) {
+                acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                    __builtin_bit_cast(f16x8, fc[b][tc]), __builtin_bit_cast(f16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
+            } else {
+                acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, fc[b][tc]), __builtin_bit_cast(bf16x8, fr[b][tr]), acc[tr][tc], 0, 0, 0);
+            }
+        };
+        // the sub-step's WM*WN MFMA groups with pieces [P0, P0+NP) of the refill slotted in after the first NP groups:
+        // a burst of 8 DMA issues right after the barrier kept BOTH waves of a SIMD out of the MFMA pipe for ~600 cycles
+        // per K-step (probes: wave 0 waits 1.1k cycles at the barrier, 55 on the DMA landing, 40 on its LDS fragments).
+        auto mfmas = [&](int b, auto P0C, auto NPC, bool dma) {
+            constexpr int P0 = decltype(P0C)::value, NP = decltype(NPC)::value;
+            static_assert(NP <= WM * WN, "");
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (([&] {
+                     mfma_one(b, std::integral_constant<int, I / WN>{}, std::integral_constant<int, I % WN>{});
+                     if constexpr (I < NP) {
+                         __builtin_amdgcn_sched_barrier(0);
+                         if (dma) piece(std::integral_constant<int, P0 + I>{});
+                         __builtin_amdgcn_sched_barrier(0);
+                     }
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, WM * WN>{});
+        };
+        using IC0 = std::integral_constant<int, 0>;
         static_assert(NSUB % 2 == 0, "fragment buffer parity must repeat every K-step");
         // prologue: stage 0 landed and visible, stage 1 in flight, fragments of (K-step 0, sub-step 0) in flight
         stage_next(0);
@@ -427,30 +454,72 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
         TRACE(2);
         if (nkt > 1) stage_next(1);
         issue(0, 0, 0);
+#ifdef LAFF_GEMM_TRACE
+        unsigned long long tw_lds = 0, tw_vm = 0, tw_bar = 0;
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_readcyclecounter();
+#endif
         for (int kt = 0; kt < nkt; ++kt) {
             if (kt == 1) TRACE(3);
+            // sub-steps 0 .. NSUB-2; the first two also carry the rest of the refill started at the previous barrier
 #pragma unroll
             for (int ks = 0; ks < NSUB - 1; ++ks) {
                 issue(kt, ks + 1, (ks + 1) & 1);
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                mfmas(ks & 1);
+                if (ks == 0) mfmas(ks & 1, std::integral_constant<int, NP0>{}, std::integral_constant<int, NP1>{}, fill_on);
+                else if (ks == 1) mfmas(ks & 1, std::integral_constant<int, NP0 + NP1>{}, std::integral_constant<int, NP2>{}, fill_on);
+                else mfmas(ks & 1, IC0{}, IC0{}, false);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // last sub-step: its fragments are the only LDS reads outstanding
+            fill_on = false;
             if (kt + 1 < nkt) {
+#ifdef LAFF_GEMM_TRACE
+                // wait breakdown of wave 0 (debug build): LDS fragments / LDS-DMA landing / barrier skew, summed over the K loop
+                const unsigned long long t_a = __builtin_readcyclecounter();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long t_b = __builtin_readcyclecounter();
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long t_c = __builtin_readcyclecounter();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const unsigned long long t_d = __builtin_readcyclecounter();
+                tw_lds += t_b - t_a; tw_vm += t_c - t_b; tw_bar += t_d - t_c;
+#else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (kt + 2 < nkt) stage_next(kt & 1);                // slot of stage kt is free now
+#endif
+                if (kt + 2 < nkt) {                                  // slot of stage kt is free now: start refilling it
+#ifndef LAFF_ABL_NODMA
+                    fill_on = true;
+#endif
+                    fill_sa = lds0 + (unsigned)(kt & 1) * CF::STAGEB;
+                    const unsigned long long kb0 = (unsigned long long)((long)st_kin * ROWB);
+                    fillR = uniform64(curR + kb0);
+                    fillC = uniform64(curC + kb0);
+                    if (++st_kin == kt_per_seg) {                    // wave-uniform
+                        st_kin = 0;
+                        ++st_seg;
+                        curR = st_seg == 1 ? nR1 : nR2;
+                        curC = st_seg == 1 ? nC1 : nC2;
+                    }
+                }
                 issue(kt + 1, 0, 0);
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfmas((NSUB - 1) & 1);
+            mfmas((NSUB - 1) & 1, IC0{}, std::integral_constant<int, NP0>{}, fill_on);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef LAFF_GEMM_TRACE
+        if (a.trace && tid == 0) {
+            unsigned long long* t2 = a.trace + (long)gridDim.x * 8 + (long)blockIdx.x * 8;
+            t2[0] = tw_lds; t2[1] = tw_vm; t2[2] = tw_bar; t2[3] = (unsigned long long)nkt;
+            t2[4] = rt0; t2[5] = __builtin_amdgcn_s_memrealtime(); t2[6] = ct0; t2[7] = __builtin_readcyclecounter();
+        }
+#endif
     } else {
         // ---- generic staging paths: compiler-scheduled loop, one barrier pair per K-step ------------------------------
         stage_next(0);
