@@ -12,6 +12,8 @@
  *   - calls are asynchronous and ordered on the stream bound to the ctx (laff_ctx_set_stream);
  *     only laff_rank_metrics / laff_device_info synchronise;
  *   - return value: 0 = LAFF_OK, negative = error; laff_last_error() returns the thread-local message;
+ *   - an EMPTY problem (N = 0 rows / B = 0 videos / Nt = 0 or Nv = 0) is legal everywhere -- the reference meets it as an
+ *     empty last batch or an empty query set: the call returns LAFF_OK without launching or touching any pointer;
  *   - a ctx is not thread-safe; distinct ctxs are independent.  No exceptions cross this boundary.
  */
 #ifndef LAFF_HIP_H

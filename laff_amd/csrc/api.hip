@@ -117,6 +117,7 @@ int laff_device_info(laff_ctx* ctx, int out[4]) {
 }
 
 static int fc_problem_args(const laff_fc_problem& q, laff::GemmArgs& a, bool& glds, const char* who) {
+    if (q.N == 0) { a = laff::GemmArgs{}; glds = true; return LAFF_OK; }      /* empty problem (skipped by the callers) */
     if (!q.X || !q.W || !q.Y) return fail(LAFF_E_ARG, "%s: null X/W/Y", who);
     if (q.N < 0 || q.Dk < 1 || q.D < 1 || q.ldx < q.Dk || q.ldw < q.Dk || q.ldy < q.D)
         return fail(LAFF_E_SHAPE, "%s: bad shape N=%d Dk=%d D=%d ldx=%d ldw=%d ldy=%d", who, q.N, q.Dk, q.D, q.ldx, q.ldw, q.ldy);
@@ -169,6 +170,7 @@ int laff_fc_gather_act_bn(laff_ctx* ctx, const int* indptr, const int* indices, 
                           const float* Wt, int ldwt, const float* bias, const float* bn_scale, const float* bn_shift, int D,
                           int act, float* Y, int ldy) {
     CHECK_CTX(ctx);
+    if (N == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!indptr || !indices || !Wt || !Y) return fail(LAFF_E_ARG, "laff_fc_gather_act_bn: null argument");
     if (N < 0 || Dk < 1 || D < 4 || (D & 3) || D > 8192 || ldwt < D || (ldwt & 3) || ldy < D || (ldy & 3))
         return fail(LAFF_E_SHAPE, "laff_fc_gather_act_bn: bad shape N=%d Dk=%d D=%d ldwt=%d ldy=%d", N, Dk, D, ldwt, ldy);
@@ -263,6 +265,7 @@ int laff_split_rows_bytes(int N, int K, size_t* out) {
 
 int laff_split_rows(laff_ctx* ctx, const float* X, int N, int K, int ldx, void* out, float* rscale) {
     CHECK_CTX(ctx);
+    if (N == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!X || !out || !rscale) return fail(LAFF_E_ARG, "laff_split_rows: null argument");
     if (N < 0 || K < 1 || ldx < K) return fail(LAFF_E_SHAPE, "laff_split_rows: bad shape N=%d K=%d ldx=%d", N, K, ldx);
     if (!aligned16(out)) return fail(LAFF_E_ALIGN, "laff_split_rows: out must be 16-byte aligned");
@@ -336,6 +339,7 @@ int laff_fuse(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int 
 int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
                      const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale) {
     CHECK_CTX(ctx);
+    if (N == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (E16 && precision != LAFF_PREC_FP16 && precision != LAFF_PREC_BF16)
         return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed: E16 is a single-plane operand (FP16 or BF16), got precision %d", precision);
     if (E16 && !aligned16(E16)) return fail(LAFF_E_ALIGN, "laff_fuse_packed: E16 must be 16-byte aligned");
@@ -372,6 +376,7 @@ int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int 
 int laff_frame_fuse(laff_ctx* ctx, const float* frames, const int* lens, int B, int Fmax, int d, const float* w,
                     const float* b, const float* gw, unsigned flags, float* V) {
     CHECK_CTX(ctx);
+    if (B == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!frames || !w || !b || !V) return fail(LAFF_E_ARG, "laff_frame_fuse: null frames/w/b/V");
     if (B < 0 || Fmax < 1 || d < 4 || (d & 3) || d > 1024)
         return fail(LAFF_E_SHAPE, "laff_frame_fuse: need B>=0, Fmax>=1, d%%4==0, d<=1024 (B=%d Fmax=%d d=%d)", B, Fmax, d);
@@ -395,6 +400,7 @@ int laff_packed_bytes(int N, int K, int precision, size_t* out) {
 int laff_pack_rows(laff_ctx* ctx, const float* E, int N, int H, int d, int lde, int normalize, float eps, float prescale,
                    int precision, void* out) {
     CHECK_CTX(ctx);
+    if (N == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!E || !out) return fail(LAFF_E_ARG, "laff_pack_rows: null E/out");
     if (N < 0 || H < 1 || d < 1 || lde < H * d)
         return fail(LAFF_E_SHAPE, "laff_pack_rows: bad shape N=%d H=%d d=%d lde=%d", N, H, d, lde);
@@ -411,6 +417,7 @@ int laff_pack_rows(laff_ctx* ctx, const float* E, int N, int H, int d, int lde, 
 int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
                   float* S, int lds, const int* gt_col, int col0, const float* s_gt, int* count) {
     CHECK_CTX(ctx);
+    if (Nt == 0 || Nv == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!T || !V) return fail(LAFF_E_ARG, "laff_sim_gemm: null T/V");
     if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "laff_sim_gemm: bad precision %d", precision);
     const int kmul = precision == LAFF_PREC_FP32 ? 32 : 64;
@@ -445,6 +452,7 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
 
 int laff_gather_gt(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt) {
     CHECK_CTX(ctx);
+    if (Nt == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!S || !gt_col || !s_gt) return fail(LAFF_E_ARG, "laff_gather_gt: null argument");
     if (Nt < 0 || Nv < 0 || lds < Nv) return fail(LAFF_E_SHAPE, "laff_gather_gt: bad shape");
     if (Nt == 0) return LAFF_OK;
@@ -456,6 +464,7 @@ int laff_gather_gt(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const
 int laff_rank_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0,
                     const float* s_gt, int* count, int accumulate) {
     CHECK_CTX(ctx);
+    if (Nt == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!S || !gt_col || !s_gt || !count) return fail(LAFF_E_ARG, "laff_rank_count: null argument");
     if (Nt < 0 || Nv < 0 || lds < Nv) return fail(LAFF_E_SHAPE, "laff_rank_count: bad shape");
     if (Nt == 0) return LAFF_OK;
@@ -466,6 +475,7 @@ int laff_rank_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, cons
 
 int laff_topk_rows(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, int K, int* idx_out, float* val_out) {
     CHECK_CTX(ctx);
+    if (Nt == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!S || !idx_out || !val_out) return fail(LAFF_E_ARG, "laff_topk_rows: null argument");
     if (Nt < 0 || Nv < 1 || lds < Nv || K < 1 || K > Nv || K > 2048) return fail(LAFF_E_SHAPE, "laff_topk_rows: need 1 <= K <= min(Nv, 2048) (Nt=%d Nv=%d K=%d)", Nt, Nv, K);
     if ((size_t)Nv * 4 + 2048 * 8 + 2048 > 160 * 1024) return fail(LAFF_E_UNSUPPORTED, "laff_topk_rows: Nv=%d does not fit the LDS-resident row (max ~36k columns per shard)", Nv);
@@ -478,6 +488,7 @@ int laff_topk_rows(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, int K
 int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx,
                    int max_group, int* count) {
     CHECK_CTX(ctx);
+    if (Nt == 0 || Nv == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!S || !grp_off || !grp_idx || !count) return fail(LAFF_E_ARG, "laff_v2t_count: null argument");
     if (Nt < 0 || Nv < 0 || lds < Nv || max_group < 0) return fail(LAFF_E_SHAPE, "laff_v2t_count: bad shape");
     if (Nt == 0 || Nv == 0 || max_group == 0) return LAFF_OK;
@@ -489,6 +500,7 @@ int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const
 int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
                     const int* gt_col, int col0, float* s_gt) {
     CHECK_CTX(ctx);
+    if (Nt == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!T || !V || !gt_col || !s_gt) return fail(LAFF_E_ARG, "laff_row_dot_gt: null argument");
     if (precision < LAFF_PREC_FP16 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_UNSUPPORTED, "laff_row_dot_gt: 16-bit precisions only (got %d)", precision);
     if (Nt < 0 || Nv < 0 || K < 8 || (K & 7)) return fail(LAFF_E_SHAPE, "laff_row_dot_gt: need K%%8==0 (K=%d)", K);

@@ -520,3 +520,62 @@ def test_margin_loss_module_plugs_into_autograd_and_2d_inputs():
     with pytest.raises(ValueError):
         from laff_amd import ops
         ops.margin_loss(s.detach(), im.detach()[:, :32], 0.2)
+
+
+# ---------------------------------------------------------------------------------------------- empty / degenerate inputs
+def test_empty_inputs_are_accepted_everywhere():
+    """N = 0 on any side is legal in the reference (an empty last batch / an empty query set): nothing is launched, shapes hold."""
+    from laff_amd import ops
+    W = dev(rnd(1).normal(0, 1, (32, 16)).astype(np.float32))
+    y = ops.fc_act_bn(torch.empty((0, 16), device=DEV), W, None, None, None, 'tanh')
+    assert y.shape == (0, 32)
+    E = ops.fuse([(torch.empty((0, 64), device=DEV), False, None, None)] * 2, 1, 64, dev(np.zeros((1, 64))), dev(np.zeros(1)),
+                 dev(np.zeros(1)), ops.attention_flags())
+    assert E.shape[0] == 0
+    T = ops.pack_rows(torch.empty((0, 64), device=DEV), True, 1e-13, 'fp16')
+    V = ops.pack_rows(dev(rnd(2).normal(0, 1, (5, 64)).astype(np.float32)), True, 1e-13, 'fp16')
+    assert ops.sim_gemm(T, V).shape == (0, 5)
+    assert ops.sim_gemm(V, T).shape == (5, 0)
+    S = torch.empty((0, 5), device=DEV)
+    gt = torch.empty((0,), dtype=torch.int32, device=DEV)
+    assert ops.rank_count(S, gt, ops.gather_gt(S, gt)).shape == (0,)
+    x = torch.sparse_csr_tensor(torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(0, dtype=torch.int32, device=DEV),
+                                torch.zeros(0, device=DEV), size=(0, 16))
+    assert ops.fc_gather_act_bn(x, dev(np.zeros((16, 32)))).shape == (0, 32)
+
+
+def test_zero_vectors_follow_the_reference_l2norm():
+    """An all-zero embedding has norm 0: l2norm divides by eps + 1e-14 and yields zeros, so its scores are exactly 0
+    (loss.py:8-13) -- on every precision path."""
+    from laff_amd import ops
+    g = rnd(5)
+    t = g.normal(0, 1, (9, 64)).astype(np.float32)
+    v = g.normal(0, 1, (7, 64)).astype(np.float32)
+    t[3] = 0
+    v[0] = 0
+    ref = O.txt2vis_matrix(t, v)
+    assert np.all(ref[3] == 0) and np.all(ref[:, 0] == 0)
+    for prec, tol in PREC_TOL.items():
+        S = ops.sim_gemm(ops.pack_rows(dev(t), True, 1e-13, prec), ops.pack_rows(dev(v), True, 1e-13, prec)).cpu().numpy()
+        assert np.all(S[3] == 0) and np.all(S[:, 0] == 0), prec
+        assert np.abs(S - ref).max() <= max(tol, 4e-4), prec
+
+
+def test_frame_fuse_degenerate_videos():
+    """A video whose frames are all padding (len 0) and a one-frame video, against the oracle (model/model.py:2147-2190)."""
+    from laff_amd import ops
+    g = rnd(8)
+    B, F, d = 5, 6, 64
+    lens = np.array([0, 1, 6, 3, 0], np.int32)
+    frames = np.zeros((B, F, d), np.float32)
+    for i in range(B):
+        frames[i, :lens[i]] = g.normal(0, 1, (lens[i], d))
+    w = g.normal(0, 0.2, d).astype(np.float32)
+    b, gw = np.float32(0.1), np.float32(0.6)
+    for name, (with_ave, mul) in O.FRAME_ATTENTION_FLAGS.items():
+        got = ops.frame_fuse(dev(frames), dev(lens, torch.int32), dev(w), dev(b).view(1), dev(gw).view(1),
+                             ops.attention_flags(with_ave, mul)).cpu().numpy()
+        ref = O.frame_attention(frames, w, b, with_ave, mul, gw)
+        assert np.array_equal(np.isfinite(got), np.isfinite(ref)), name
+        m = np.isfinite(ref)
+        assert np.abs(got[m] - ref[m]).max() <= 2e-6, name
