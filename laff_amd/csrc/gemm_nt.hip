@@ -576,6 +576,215 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
 #undef TRACE
 }
 
+// ---- hi/lo split products with the three partial products INTERLEAVED per K-step ("x3" tile) -----------------------
+// The virtual-K concatenation above streams [lo|hi|hi] . [hi|lo|hi]: every hi plane crosses L2 -> LDS -> registers twice.
+// Here a stage holds the four planes (R_hi, R_lo, C_hi, C_lo) of ONE 32-element K-step (64-byte rows, 4 x 16 KiB) and each
+// 16-element slice runs three MFMA groups on them:
+//     B: R_hi . C_lo        C: R_hi . C_hi        A: R_lo . C_hi
+// with fragment sets arranged so that C reuses B's R_hi fragments and A reuses C's C_hi fragments: 12 fragment reads per
+// 24 MFMAs (0.5 per MFMA instead of 0.75), 64 KiB of LDS-DMA per 48 MFMAs per wave instead of per 32, one barrier per 48.
+// LDS reads and the refill DMA are what bound the K loop, so this is where the split GEMM gains.
+struct CfgX3 {
+    static constexpr int WM = 4, WN = 2, WR = 2, WC = 4;
+    static constexpr int TR = 256, TC = 256, THREADS = 512;
+    static constexpr int ROWB = 64, CPR = 4;                       // one K-step = 32 16-bit elements
+    static constexpr int PLB = TR * ROWB;                          // one plane of one operand: 16 KiB
+    static constexpr int OPB_R = 2 * PLB, OPB_C = 2 * PLB, STAGEB = OPB_R + OPB_C, SMEM = 2 * STAGEB;
+    static constexpr int PITCH = WN * 32 + 4;
+    static constexpr int WPS = 2;
+    static_assert(THREADS / 64 * 32 * PITCH * 4 <= SMEM, "epilogue slabs must fit in the operand ring");
+};
+
+template <int MODE, int EPI>
+__device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int lin, char* smem) {
+    static_assert(MODE == GEMM_F16 || MODE == GEMM_BF16, "the split product runs on the 16-bit matrix pipe");
+    using CF = CfgX3;
+    constexpr int WM = CF::WM, WN = CF::WN, THREADS = CF::THREADS, RB = CF::ROWB, CPR = CF::CPR;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / CF::WC, wc = wave % CF::WC;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
+    const int gsz_full = 8 * tiles_c;
+    const int grp = lin / gsz_full;
+    const int first_r = grp * 8;
+    const int gsz = min(tiles_r - first_r, 8);
+    const int in_grp = lin - grp * gsz_full;
+    const int tile_r = first_r + in_grp % gsz;
+    const int tile_c = in_grp / gsz;
+    const int r0 = tile_r * CF::TR, c0 = tile_c * CF::TC;
+
+    const long ldRb = (long)a.ldR * 2, ldCb = (long)a.ldC * 2;
+    const int nkt = (int)(((long)a.K * 2) / RB);                  // K bytes are a multiple of 128 on this path
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+    // per-lane source offsets inside a plane: slot p = sub*THREADS + tid -> (row p/4, swizzled chunk); the same for hi and lo
+    unsigned offR[2], offC[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int p = sub * THREADS + tid, row = p / CPR, ch = (p % CPR) ^ ((row >> 2) & 3);
+        offR[sub] = (unsigned)min(r0 + row, a.nR - 1) * (unsigned)ldRb + (unsigned)ch * 16u;
+        offC[sub] = (unsigned)min(c0 + row, a.nC - 1) * (unsigned)ldCb + (unsigned)ch * 16u;
+    }
+    // planes: segments of the concatenated formulation are (R_lo, C_hi), (R_hi, C_lo), (R_hi, C_hi)
+    const unsigned long long bRhi = (unsigned long long)((const char*)a.R + a.segR[1]), bRlo = (unsigned long long)((const char*)a.R + a.segR[0]);
+    const unsigned long long bChi = (unsigned long long)((const char*)a.C + a.segC[0]), bClo = (unsigned long long)((const char*)a.C + a.segC[1]);
+    unsigned long long fRhi = 0, fRlo = 0, fChi = 0, fClo = 0;     // wave-uniform source bases of the stage being filled
+    unsigned fill_sa = 0;
+    bool fill_on = false;
+    const unsigned wbase = (unsigned)(tid & ~63) * 16u;
+    auto fill_begin = [&](int kt, int buf) {
+        const unsigned long long kb = (unsigned long long)((long)kt * RB);
+        fRhi = uniform64(bRhi + kb); fRlo = uniform64(bRlo + kb); fChi = uniform64(bChi + kb); fClo = uniform64(bClo + kb);
+        fill_sa = lds0 + (unsigned)buf * CF::STAGEB;
+    };
+    // piece pc = operand*4 + plane*2 + sub (operand 0 = R, plane 0 = hi)
+    auto piece = [&](auto PC) {
+        constexpr int pc = decltype(PC)::value, op = pc >> 2, plane = (pc >> 1) & 1, sub = pc & 1;
+        const unsigned dst = fill_sa + (unsigned)(op * CF::OPB_R + plane * CF::PLB + sub * (THREADS * 16)) + wbase;
+        const unsigned long long base = op == 0 ? (plane == 0 ? fRhi : fRlo) : (plane == 0 ? fChi : fClo);
+        glds_piece(op == 0 ? offR[sub] : offC[sub], base, __builtin_amdgcn_readfirstlane(dst));
+    };
+    auto fill_all = [&]() {
+        piece(std::integral_constant<int, 0>{}); piece(std::integral_constant<int, 1>{});
+        piece(std::integral_constant<int, 2>{}); piece(std::integral_constant<int, 3>{});
+        piece(std::integral_constant<int, 4>{}); piece(std::integral_constant<int, 5>{});
+        piece(std::integral_constant<int, 6>{}); piece(std::integral_constant<int, 7>{});
+    };
+
+    // fragment reads: row base + swizzled chunk (2*ks + hh) of the 64-byte row; plane / stage / 32-row block as offsets
+    const unsigned laneR = lds0 + (unsigned)(wr * (WM * 32) + l31) * RB;
+    const unsigned laneC = lds0 + CF::OPB_R + (unsigned)(wc * (WN * 32) + l31) * RB;
+    unsigned xk[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) xk[ks] = (unsigned)(((2 * ks + hh) ^ ((l31 >> 2) & 3)) * 16);
+    u32x4 fc[2][WN], fr[2][WM];
+    auto rd_fc = [&](int set, int kt, int ks, int plane) {
+        const unsigned ac = laneC + (unsigned)(kt & 1) * CF::STAGEB + (unsigned)plane * CF::PLB + xk[ks];
+#pragma unroll
+        for (int t = 0; t < WN; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fc[set][t]) : "v"(ac), "n"(t * 32 * RB));
+    };
+    auto rd_fr = [&](int set, int kt, int ks, int plane) {
+        const unsigned ar = laneR + (unsigned)(kt & 1) * CF::STAGEB + (unsigned)plane * CF::PLB + xk[ks];
+#pragma unroll
+        for (int t = 0; t < WM; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[set][t]) : "v"(ar), "n"(t * 32 * RB));
+    };
+    // WM*WN MFMAs on (fc[FS], fr[RS]) with refill pieces [P0, P0+NP) slotted in after the first NP of them
+    auto mm = [&](auto FSC, auto RSC, auto P0C, auto NPC, bool dma) {
+        constexpr int FS = decltype(FSC)::value, RS = decltype(RSC)::value, P0 = decltype(P0C)::value, NP = decltype(NPC)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 constexpr int tr = I / WN, tc = I % WN;
+                 if constexpr (MODE == GEMM_F16)
+                     acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fc[FS][tc]),
+                                                                          __builtin_bit_cast(f16x8, fr[RS][tr]), acc[tr][tc], 0, 0, 0);
+                 else
+                     acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fc[FS][tc]),
+                                                                           __builtin_bit_cast(bf16x8, fr[RS][tr]), acc[tr][tc], 0, 0, 0);
+                 if constexpr (I < NP) {
+                     __builtin_amdgcn_sched_barrier(0);
+                     if (dma) piece(std::integral_constant<int, P0 + I>{});
+                     __builtin_amdgcn_sched_barrier(0);
+                 }
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, WM * WN>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    using I6 = std::integral_constant<int, 6>;
+
+    // prologue: stage 0 landed and visible, stage 1 in flight, operands of the first B group (C_lo, R_hi of slice 0) in flight
+    fill_begin(0, 0);
+    fill_all();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (nkt > 1) { fill_begin(1, 1); fill_all(); }
+    rd_fc(1, 0, 0, 1);
+    rd_fr(1, 0, 0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // ---- B: R_hi . C_lo (set 1); meanwhile fetch C_hi -> fc[0], R_lo -> fr[0] of this slice
+            rd_fc(0, kt, ks, 0);
+            rd_fr(0, kt, ks, 1);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            if (ks == 0) mm(I1{}, I1{}, I4{}, I2{}, fill_on);      // pieces 4,5 of the refill started at the previous barrier
+            else mm(I1{}, I1{}, I0{}, I0{}, false);
+            bool nx = true;                                        // is there a next 16-element slice?
+            int nkt_ = kt, nks = 1;
+            if (ks == 1) {
+                nx = kt + 1 < nkt;
+                nkt_ = kt + 1; nks = 0;
+                if (nx) {
+                    // every wave has read all it needs from stage kt (the fetches above have landed) and stage kt+1 has landed
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    fill_on = kt + 2 < nkt;
+                    if (fill_on) fill_begin(kt + 2, kt & 1);
+                }
+            }
+            // ---- C: R_hi . C_hi (fr[1], fc[0]); meanwhile fetch the next slice's C_lo -> fc[1]
+            if (nx) {
+                rd_fc(1, nkt_, nks, 1);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            }
+            if (ks == 0) mm(I0{}, I1{}, I6{}, I2{}, fill_on);      // pieces 6,7
+            else mm(I0{}, I1{}, I0{}, I2{}, fill_on);              // pieces 0,1 of the refill just started
+            if (ks == 0) fill_on = false;
+            // ---- A: R_lo . C_hi (fr[0], fc[0]); meanwhile fetch the next slice's R_hi -> fr[1]
+            if (nx) {
+                rd_fr(1, nkt_, nks, 0);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (ks == 0) mm(I0{}, I0{}, I0{}, I0{}, false);
+            else mm(I0{}, I0{}, I2{}, I2{}, fill_on);              // pieces 2,3
+        }
+    }
+
+    __syncthreads();                                   // every wave is done reading the operand ring
+    const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
+                      ((((uintptr_t)a.out) & 15) == 0);
+    if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(CfgX3::THREADS, CfgX3::WPS) void gemm_nt_x3_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_r = (a.nR + CfgX3::TR - 1) / CfgX3::TR, tiles_c = (a.nC + CfgX3::TC - 1) / CfgX3::TC;
+    gemm_tile_x3<MODE, EPI_SIM>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), smem);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(CfgX3::THREADS, CfgX3::WPS) void gemm_nt_x3_grouped_kernel(GroupedGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lin = xcd_remap(blockIdx.x, g.tile_start[g.count]);
+    int p = 0;
+    while (p + 1 < g.count && lin >= g.tile_start[p + 1]) ++p;     // wave-uniform scalar search
+    gemm_tile_x3<MODE, EPI_FC>(g.p[p], lin - g.tile_start[p], smem);
+}
+
 template <int MODE, int STG, typename CF>
 __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -624,7 +833,8 @@ int staging_kind(const GemmArgs& a, int esz, bool aligned) {
     return 1;
 }
 
-int g_gemm_variant = 0;   // tuning knob LAFF_GEMM_VARIANT: 128 / 256 force the tile configuration of the 16-bit GEMM
+int g_gemm_variant = 0;   // tuning knob LAFF_GEMM_VARIANT: 128 / 256 force the tile configuration of the 16-bit GEMM (256 also
+                          // keeps split products in the concatenated form); 3 forces the big tiles incl. the interleaved x3 tile
 
 template <int MODE>
 static hipError_t launch_m(const GemmArgs& a, bool aligned, hipStream_t st) {
@@ -634,7 +844,8 @@ static hipError_t launch_m(const GemmArgs& a, bool aligned, hipStream_t st) {
     if constexpr (MODE != GEMM_F32) {
         // big tiles when there are enough of them to fill 256 CUs a few times over
         const long tiles256 = (long)((a.nR + 255) / 256) * ((a.nC + 255) / 256);
-        const bool big = g_gemm_variant == 256 || (g_gemm_variant != 128 && tiles256 >= 512);
+        const bool big = g_gemm_variant == 256 || g_gemm_variant == 3 || (g_gemm_variant != 128 && tiles256 >= 512);
+        if (big && a.nseg == 3 && g_gemm_variant != 256) return launch_x3<MODE>(a, st);
         if (big) return launch_t<MODE, 2, Cfg256>(a, st);
     }
     return launch_t<MODE, 2, Cfg128>(a, st);
@@ -672,10 +883,47 @@ static hipError_t launch_grouped_f16_t(GroupedGemmArgs& g, hipStream_t st) {
     return hipGetLastError();
 }
 
+static hipError_t launch_grouped_x3(GroupedGemmArgs& g, hipStream_t st) {
+    long nb = 0;
+    for (int i = 0; i < g.count; ++i) {
+        g.tile_start[i] = (int)nb;
+        nb += (long)((g.p[i].nR + CfgX3::TR - 1) / CfgX3::TR) * ((g.p[i].nC + CfgX3::TC - 1) / CfgX3::TC);
+    }
+    if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
+    g.tile_start[g.count] = (int)nb;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = set_smem(gemm_nt_x3_grouped_kernel<GEMM_F16>, CfgX3::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_x3_grouped_kernel<GEMM_F16>), dim3((unsigned)nb), dim3(CfgX3::THREADS), CfgX3::SMEM, st, g);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_x3(const GemmArgs& a, hipStream_t st) {
+    const long nb = (long)((a.nR + CfgX3::TR - 1) / CfgX3::TR) * ((a.nC + CfgX3::TC - 1) / CfgX3::TC);
+    if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = set_smem(gemm_nt_x3_kernel<MODE>, CfgX3::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_x3_kernel<MODE>), dim3((unsigned)nb), dim3(CfgX3::THREADS), CfgX3::SMEM, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_nt_grouped_f16(GroupedGemmArgs& g, hipStream_t st) {
     long t256 = 0;
-    for (int i = 0; i < g.count; ++i) t256 += (long)((g.p[i].nR + 255) / 256) * ((g.p[i].nC + 255) / 256);
-    const bool big = g_gemm_variant == 256 || (g_gemm_variant != 128 && t256 >= 512);
+    bool split = true;
+    for (int i = 0; i < g.count; ++i) {
+        t256 += (long)((g.p[i].nR + 255) / 256) * ((g.p[i].nC + 255) / 256);
+        split = split && g.p[i].nseg == 3;
+    }
+    const bool big = g_gemm_variant == 256 || g_gemm_variant == 3 || (g_gemm_variant != 128 && t256 >= 512);
+    if (big && split && g_gemm_variant != 256) return launch_grouped_x3(g, st);     // LAFF_GEMM_VARIANT=256: concatenated form
     return big ? launch_grouped_f16_t<Cfg256>(g, st) : launch_grouped_f16_t<Cfg128>(g, st);
 }
 
