@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 4
+#define LAFF_ABI_VERSION 5
 
 enum {
     LAFF_OK = 0,
@@ -129,7 +129,10 @@ int laff_margin_loss(laff_ctx* ctx, const float* s, const float* im, int B, int 
 /* ---- a2-a6: stack + Multi_head_MyApply_Attention / Attention_1 / JustAverage ----------------------------
  * (model/model.py:1858-1876, :1663-1705; model/Attention.py:508-531, :78-105)
  * One feature plane per fused feature; nothing is stacked or tiled in memory.
- *   x_l[n, h, c] = src_l[n, (tile ? c : h*d + c)] * scale_l[h*d + c] + shift_l[h*d + c]
+ *   x_l[n, h, c] = act_l( src_l[n, (tile ? c : h*d + c)] ) * scale_l[h*d + c] + shift_l[h*d + c]
+ * act (LAFF_ACT_*) lets the producing projection hand over its PRE-activation output (x W^T + b) and leave
+ * `tanh -> BatchNorm` of TransformNet (model/model.py:270-275) to this kernel (same v_exp_f32 / v_rcp_f32 arithmetic as the
+ * GEMM epilogue: identical bits either way).
  * tile != 0 restates the no-transform branch `x.repeat(1, heads)` + BatchNorm1d(D)
  * (model/model.py:1801-1805, 1822-1823; text side :659-664, 1675-1676): src has d columns. */
 typedef struct {
@@ -138,6 +141,7 @@ typedef struct {
     int tile;
     const float* scale;   /* [H*d] or NULL (=1) */
     const float* shift;   /* [H*d] or NULL (=0) */
+    int act;              /* LAFF_ACT_* applied to src before the affine (0 = none) */
 } laff_plane;
 
 /* E[N,H,d] (unit L2 norm per (n,h) unless JUST_AVERAGE).  w [H,d], b [H], gw [H] device arrays.

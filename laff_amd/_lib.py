@@ -9,11 +9,11 @@ LIB_PATH = os.environ.get('LAFF_HIP_LIB') or os.path.join(_HERE, 'lib', 'liblaff
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Plane(C.Structure):
-    _fields_ = [('src', C.c_void_p), ('ld', C.c_int), ('tile', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p)]
+    _fields_ = [('src', C.c_void_p), ('ld', C.c_int), ('tile', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p), ('act', C.c_int)]
 
 
 class FcProblem(C.Structure):

@@ -362,7 +362,8 @@ int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int 
         if (p.ld < need || (p.ld & 3)) return fail(LAFF_E_SHAPE, "laff_fuse: plane %d ld=%d (need >= %d, multiple of 4)", l, p.ld, need);
         if (!aligned16(p.src) || (p.scale && (!aligned16(p.scale) || !aligned16(p.shift))))
             return fail(LAFF_E_ALIGN, "laff_fuse: plane %d not 16-byte aligned", l);
-        a.src[l] = p.src; a.ld[l] = p.ld; a.tile[l] = p.tile; a.scale[l] = p.scale; a.shift[l] = p.shift;
+        if (p.act < LAFF_ACT_NONE || p.act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fuse: plane %d bad act %d", l, p.act);
+        a.src[l] = p.src; a.ld[l] = p.ld; a.tile[l] = p.tile; a.scale[l] = p.scale; a.shift[l] = p.shift; a.act[l] = p.act;
     }
     if (N == 0) return LAFF_OK;
     a.L = L; a.N = N; a.H = H; a.d = d; a.head_stride = nosplit ? 0 : d;

@@ -36,10 +36,23 @@ __device__ __forceinline__ float4 fma4(float4 a, float s, float4 c) {
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// x_l[n,h,col..col+3] with the plane's tiling and folded affine applied
+// the same tanh / sigmoid as the GEMM epilogue (v_exp_f32 + v_rcp_f32), so that deferring the activation of a projection
+// to this kernel leaves every bit of the result unchanged
+__device__ __forceinline__ float plane_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.885390081777927f) + 1.0f);
+}
+__device__ __forceinline__ float plane_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
+// x_l[n,h,col..col+3] with the plane's activation, tiling and folded affine applied
 __device__ __forceinline__ float4 load_plane(const FuseArgs& a, int l, long n, int h, int col) {
     const int srccol = a.tile[l] ? col : h * a.head_stride + col;
     float4 v = *(const float4*)(a.src[l] + n * a.ld[l] + srccol);
+    const int act = a.act[l];                                   // wave-uniform
+    if (act == LAFF_ACT_TANH) v = make_float4(plane_tanh(v.x), plane_tanh(v.y), plane_tanh(v.z), plane_tanh(v.w));
+    else if (act == LAFF_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    else if (act == LAFF_ACT_SIGMOID) v = make_float4(plane_sigmoid(v.x), plane_sigmoid(v.y), plane_sigmoid(v.z), plane_sigmoid(v.w));
     if (a.scale[l]) {
         const int ai = a.tile[l] ? h * a.d + col : srccol;
         const float4 s = *(const float4*)(a.scale[l] + ai);

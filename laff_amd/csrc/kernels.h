@@ -54,6 +54,7 @@ struct FuseArgs {
     const float* shift[MAX_L];
     int ld[MAX_L];
     int tile[MAX_L];
+    int act[MAX_L];       // LAFF_ACT_* applied to the plane before its affine
     int L, N, H, d;
     int head_stride;      // d (split heads) or 0 (every head sees all columns)
     const float* w;       // [H, d]

@@ -18,6 +18,8 @@ Text encoders (GRU / BoW / W2V / CLIP, :311-549) are upstream of the path: featu
 returning {'text_features': tensor} can be plugged into `txt_net.encoder.<name>`.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -39,6 +41,12 @@ def run_fc(pending):
     if FC_PRECISION != 'fp32':
         raise ValueError("FC_PRECISION must be 'fp32' or 'fp16x3'")
     return ops.fc_act_bn_grouped(pending)
+
+
+#: tower path: leave activation + BatchNorm of the FC projections to the fuse launch (see TransformNet.plane).  Off by default:
+#: measured on C4 the GEMM launch gets 0.045 ms shorter and the fuse launches 0.047 ms longer -- the two v_exp/v_rcp per element
+#: run at quarter rate wherever they sit (1.372 ms vs 1.362 ms per step over three A/B pairs on one box).
+DEFER_ACTIVATION = os.environ.get('LAFF_DEFER_ACT', '0') == '1'
 
 
 def _initialize_weights(m):
@@ -163,19 +171,25 @@ class TransformNet(nn.Module):
             prob = dict(x=x, weight=self.fc1.weight.detach(), weight_split=self.weight_split(),
                         bias=self.fc1.bias.detach() if self.fc1.bias is not None else None,
                         bn_scale=scale, bn_shift=shift, activation=self.activation_name)
-            if pending is None:
-                y = run_fc([prob])[0]
-            else:
+            if pending is None or not DEFER_ACTIVATION:
+                if pending is None:
+                    return (run_fc([prob])[0], False, None, None)
                 y = prob['out'] = torch.empty((x.shape[0], self.out_features), device=x.device, dtype=torch.float32)
                 pending.append(prob)
-            return (y, False, None, None)
+                return (y, False, None, None)
+            # tower path: the grouped GEMM writes the pre-activation x W^T + b; activation + BatchNorm ride along in the fuse
+            # launch (memory-bound, the transcendentals are free there; in the GEMM epilogue they were 17 % of the launch)
+            prob.update(bn_scale=None, bn_shift=None, activation=None)
+            y = prob['out'] = torch.empty((x.shape[0], self.out_features), device=x.device, dtype=torch.float32)
+            pending.append(prob)
+            return (y, False, scale, shift, self.activation_name)
         if self.activation_name is not None:
             raise NotImplementedError('activation without fc is never built by the reference towers')
         tile = heads > 1 and x.shape[1] * heads == self.out_features
         return (x, tile, scale, shift)
 
     def forward(self, input_x):
-        src, tile, scale, shift = self.plane(input_x)
+        src, tile, scale, shift = self.plane(input_x)[:4]
         if scale is None and not tile:
             return src
         out = ops.fuse([(src, tile, scale, shift)], 1, src.shape[1], None, None, None,
@@ -197,8 +211,9 @@ def _fuse(attention_layer, planes, heads):
 
 
 def _materialise(plane, heads, D):
-    src, tile, scale, shift = plane
-    if scale is None and not tile:
+    src, tile, scale, shift = plane[:4]
+    act = plane[4] if len(plane) > 4 else None
+    if scale is None and not tile and act is None:
         return src
     H = heads if tile else 1
     out = ops.fuse([plane], H, D // H, None, None, None, ops.attention_flags(just_average=True))

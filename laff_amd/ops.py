@@ -257,13 +257,17 @@ def fc_act_bn_split_grouped(problems):
 
 
 def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=None):
-    """planes: list of (src[N, ld-view], tile, scale, shift).  Returns E (N, H, d) [and softmax weights (N, H, L)].
+    """planes: list of (src[N, ld-view], tile, scale, shift[, act]) -- act ('tanh' | 'relu' | 'sigmoid' | None) is applied to src
+    before the affine (a projection that left its activation + BatchNorm to this kernel).  Returns E (N, H, d) [and softmax
+    weights (N, H, L)].
     packed_precision ('fp16' | 'bf16'): also emit the similarity operand in the same launch; returned last."""
     L = len(planes)
     arr = (Plane * L)()
     N = planes[0][0].shape[0]
     keep = []
-    for i, (src, tile, scale, shift) in enumerate(planes):
+    for i, pl in enumerate(planes):
+        src, tile, scale, shift = pl[:4]
+        act = pl[4] if len(pl) > 4 else None
         src, ld = _rows(src, 'plane %d' % i)
         if src.shape[0] != N:
             raise ValueError('plane %d has %d rows, expected %d' % (i, src.shape[0], N))
@@ -274,7 +278,7 @@ def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=N
             if t is not None:
                 _dev(t, 'plane affine')
         arr[i] = Plane(src.data_ptr(), ld, 1 if tile else 0, scale.data_ptr() if scale is not None else None,
-                       shift.data_ptr() if shift is not None else None)
+                       shift.data_ptr() if shift is not None else None, ACT[act])
         keep.append((src, scale, shift))
     dev = planes[0][0].device
     E = torch.empty((N, H, d), device=dev, dtype=torch.float32)

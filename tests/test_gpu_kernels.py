@@ -579,3 +579,24 @@ def test_frame_fuse_degenerate_videos():
         assert np.array_equal(np.isfinite(got), np.isfinite(ref)), name
         m = np.isfinite(ref)
         assert np.abs(got[m] - ref[m]).max() <= 2e-6, name
+
+
+@pytest.mark.parametrize('act', ['tanh', 'relu', 'sigmoid'])
+def test_fuse_plane_activation_equals_activation_in_the_projection(act):
+    """plane.act: a projection may hand over x W^T + b and leave activation + BatchNorm to laff_fuse -- same bits."""
+    from laff_amd import ops
+    g = rnd(31)
+    N, Dk, H, d = 70, 96, 2, 64
+    D = H * d
+    xs = [dev(g.normal(0, 1, (N, Dk)).astype(np.float32)) for _ in range(3)]
+    Ws = [dev((g.normal(0, 1, (D, Dk)) / 8).astype(np.float32)) for _ in range(3)]
+    bs = [dev(g.normal(0, 0.1, D).astype(np.float32)) for _ in range(3)]
+    sc = [dev(g.uniform(0.5, 1.5, D).astype(np.float32)) for _ in range(3)]
+    sh = [dev(g.normal(0, 0.1, D).astype(np.float32)) for _ in range(3)]
+    w, b, gw = dev(g.normal(0, 0.2, (H, d)).astype(np.float32)), dev(g.normal(0, 0.1, H).astype(np.float32)), dev(np.full(H, 0.6, np.float32))
+    flags = ops.attention_flags(with_ave=True)
+    fused_in_fc = [(ops.fc_act_bn(x, W, bb, s, t, act), False, None, None) for x, W, bb, s, t in zip(xs, Ws, bs, sc, sh)]
+    deferred = [(ops.fc_act_bn(x, W, bb, None, None, None), False, s, t, act) for x, W, bb, s, t in zip(xs, Ws, bs, sc, sh)]
+    E1 = ops.fuse(fused_in_fc, H, d, w, b, gw, flags)
+    E2 = ops.fuse(deferred, H, d, w, b, gw, flags)
+    assert torch.equal(E1, E2)
