@@ -321,8 +321,10 @@ def main():
                     tj.get('fc_precision') == args.fc_precision and dom in tj['kernels'] and world == 1):
                 k = tj['kernels'][dom]
                 roof['traffic'] = round((k['fetch_corrected_MB'] + k['write_MB']) * 1e6)
+                alg = sim_bytes if dom == 'sim_gemm' else (work[dom][1] if work.get(dom, ('', 0))[0] == 'hbm' else None)
                 roof['traffic_note'] = ('bytes per launch: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), rocprofv3 --pmc passes '
-                                        'of this command, profiles/r1_bench_pmc_*.txt; algorithmic %.0f MB' % k.get('algorithmic_MB', 0))
+                                        'of this command (tools/profile_round.sh), profiles/r1_bench_pmc_*.txt'
+                                        + ('; algorithmic %.0f MB' % (alg / 1e6) if alg else ''))
         except Exception:  # noqa: BLE001
             pass
         m = res['metrics']

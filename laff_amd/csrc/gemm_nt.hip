@@ -833,6 +833,9 @@ int staging_kind(const GemmArgs& a, int esz, bool aligned) {
     return 1;
 }
 
+template <int MODE>
+static hipError_t launch_x3(const GemmArgs& a, hipStream_t st);
+
 int g_gemm_variant = 0;   // tuning knob LAFF_GEMM_VARIANT: 128 / 256 force the tile configuration of the 16-bit GEMM (256 also
                           // keeps split products in the concatenated form); 3 forces the big tiles incl. the interleaved x3 tile
 

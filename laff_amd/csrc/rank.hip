@@ -185,122 +185,122 @@ __device__ __forceinline__ int block_sum_int(int v, int* sh) {
     return t;
 }
 
-// The median is an order statistic of small positive integers: MSB-first radix select with 12-bit digits, starting at the
-// top set bit of the largest rank (two passes for ranks < 2^24), on ranks cached in registers.  (A first version bisected on
-// the value: 14 rounds of compare + block reduction, 68 us for 40,000 ranks -- 5 % of a whole C4 step.)
+// The median is an order statistic of positive integers: MSB-first radix select with 8-bit digits, starting at the top
+// non-zero byte of the largest rank (two passes for ranks < 65536).  The digit histogram lives in LDS with every bin
+// REPLICATED 32 times (replica = lane & 31, row pitch 33 words): retrieval ranks pile up on a few values (41 % are rank 1
+// at C4) and 64 lanes adding to one LDS word serialise 64-deep -- a first radix version with plain bins took 72 us, a
+// 16-way value search without atomics 55 us (one workgroup = one CU: its VALU work does not spread), bisection 68 us.
+// One workgroup, ranks streamed from L2 each pass; all reductions of a phase share one barrier pair.
 __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, double* __restrict__ out7,
                                                             int* __restrict__ err) {
-    __shared__ double sh[16];
-    __shared__ int shi[16];
-    __shared__ unsigned hist[4096];
+    __shared__ double shd[16];
+    __shared__ unsigned long long shl[16][4];
+    __shared__ int shm[16][2];
+    __shared__ unsigned hist[256 * 33];
+    __shared__ int wsum[4];
     __shared__ int sel[2];
-    constexpr int PER = 64;                 // up to 65536 ranks live in registers
-    const bool in_regs = n <= PER * 1024;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int vals[PER];
-    double c1 = 0, c5 = 0, c10 = 0, sum = 0, isum = 0;
+    // ---- sums: exact integer counters, fp64 for the reciprocal sum
+    unsigned long long c1 = 0, c5 = 0, c10 = 0, sum = 0;
+    double isum = 0;
     int mx = 0, mn = 0x7fffffff;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int i = j * 1024 + tid;
-        vals[j] = (in_regs && i < n) ? r[i] : -1;              // -1 = no element
+#pragma unroll 4
+    for (int i = tid; i < n; i += 1024) {
+        const int v = r[i];
+        c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
+        sum += (unsigned long long)(long long)v;
+        // 1/v: fp32 reciprocal refined by two Newton steps in fp64 (relative error < 1e-16) instead of a full fp64 division
+        const double d = (double)v;
+        double q = (double)__builtin_amdgcn_rcpf((float)v);
+        q = q * (2.0 - d * q);
+        q = q * (2.0 - d * q);
+        isum += q;
+        mx = max(mx, v); mn = min(mn, v);
     }
-    if (in_regs) {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int v = vals[j];
-            if (v != -1) {
-                c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
-                sum += v; isum += 1.0 / (double)v;
-                mx = max(mx, v); mn = min(mn, v);
-            }
-        }
-    } else {
-        for (int i = tid; i < n; i += 1024) {
-            const int v = r[i];
-            c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
-            sum += v; isum += 1.0 / (double)v;
-            mx = max(mx, v); mn = min(mn, v);
-        }
+    for (int o = 32; o >= 1; o >>= 1) {
+        c1 += __shfl_xor(c1, o); c5 += __shfl_xor(c5, o); c10 += __shfl_xor(c10, o); sum += __shfl_xor(sum, o);
+        isum += __shfl_xor(isum, o);
+        mx = max(mx, __shfl_xor(mx, o)); mn = min(mn, __shfl_xor(mn, o));
     }
-    c1 = block_sum(c1, sh); c5 = block_sum(c5, sh); c10 = block_sum(c10, sh);
-    sum = block_sum(sum, sh); isum = block_sum(isum, sh);
-    mx = block_max(mx, sh);
-    mn = -block_max(-mn, sh);
-    if (mn < 1) {                                               // invalid input: report, do not select
+    if (lane == 0) {
+        shl[wave][0] = c1; shl[wave][1] = c5; shl[wave][2] = c10; shl[wave][3] = sum;
+        shd[wave] = isum;
+        shm[wave][0] = mx; shm[wave][1] = mn;
+    }
+    __syncthreads();
+    mx = 0; mn = 0x7fffffff;
+    for (int w = 0; w < 16; ++w) { mx = max(mx, shm[w][0]); mn = min(mn, shm[w][1]); }
+    mx = __builtin_amdgcn_readfirstlane(mx);
+    mn = __builtin_amdgcn_readfirstlane(mn);
+    if (n > 0 && mn < 1) {                                        // invalid input: report, do not select
         if (tid == 0) err[0] = 1;
         return;
     }
-    // k-th smallest (0-based k = n/2)
+    // ---- k-th smallest (0-based k = n/2)
     const int k = n / 2;
     unsigned prefix = 0, mask = 0;
-    int less = 0;                                               // #{v < current prefix range}
-    for (int top = 32 - __clz(mx); top > 0; top -= 12) {
-        const int shift = max(0, top - 12), nb = 1 << (top - shift);
-        for (int i = tid; i < nb; i += 1024) hist[i] = 0;
+    int less = 0;                                                 // #{r < smallest value with the current prefix}
+    const int rep = lane & 31;
+    for (int shift = ((32 - __clz(mx | 1) + 7) / 8 - 1) * 8; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 256 * 33; i += 1024) hist[i] = 0;
         __syncthreads();
-        auto tally = [&](int v) {
-            if (((unsigned)v & mask) == prefix) atomicAdd(&hist[((unsigned)v >> shift) & (nb - 1)], 1u);
-        };
-        if (in_regs) {
-#pragma unroll
-            for (int j = 0; j < PER; ++j)
-                if (vals[j] != -1) tally(vals[j]);
-        } else {
-            for (int i = tid; i < n; i += 1024) tally(r[i]);
+#pragma unroll 8
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned v = (unsigned)r[i];
+            if ((v & mask) == prefix) atomicAdd(&hist[((v >> shift) & 255u) * 33 + rep], 1u);
         }
         __syncthreads();
-        // thread t owns bins [4t, 4t+4): block-wide exclusive scan of the per-thread sums, then the owner of k publishes
-        unsigned h[4], own = 0;
+        // threads 0..255: bin totals, inclusive scan over the 256 bins, the owner of k publishes its digit
+        int own = 0, inc = 0;
+        if (tid < 256) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h[e] = (4 * tid + e < nb) ? hist[4 * tid + e] : 0u;
-            own += h[e];
-        }
-        int inc = (int)own;
+            for (int q = 0; q < 32; ++q) own += (int)hist[tid * 33 + q];
+            inc = own;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            if (lane == 63) wsum[wave] = inc;
         }
-        if (lane == 63) shi[wave] = inc;
         __syncthreads();
-        int before = less + inc - (int)own;
-        for (int w = 0; w < wave; ++w) before += shi[w];
-        if (before <= k && k < before + (int)own) {             // exactly one thread
-            int e = 0;
-            while (before + (int)h[e] <= k) { before += (int)h[e]; ++e; }
-            sel[0] = 4 * tid + e;
-            sel[1] = before;
+        if (tid < 256) {
+            int before = less + inc - own;
+            for (int w = 0; w < wave; ++w) before += wsum[w];
+            if (before <= k && k < before + own) { sel[0] = tid; sel[1] = before; }     // exactly one thread
         }
         __syncthreads();
         prefix |= (unsigned)sel[0] << shift;
-        mask |= (unsigned)(nb - 1) << shift;
+        mask |= 255u << shift;
         less = sel[1];
-        __syncthreads();
     }
-    const int lo = (int)prefix;
-    double med = lo;
-    if ((n & 1) == 0) {
+    const int med_lo = (int)prefix;
+    double med = med_lo;
+    if (n > 0 && (n & 1) == 0) {
         // sorted[k-1]: equals sorted[k] unless exactly k elements are smaller, then it is the largest of those
         int below = 0;
-        if (in_regs) {
-#pragma unroll
-            for (int j = 0; j < PER; ++j)
-                if (vals[j] != -1 && vals[j] < lo) below = max(below, vals[j]);
-        } else {
-            for (int i = tid; i < n; i += 1024) {
-                const int v = r[i];
-                if (v < lo) below = max(below, v);
-            }
+#pragma unroll 8
+        for (int i = tid; i < n; i += 1024) {
+            const int v = r[i];
+            if (v < med_lo) below = max(below, v);
         }
-        below = block_max(below, sh);
-        const double prev = (less >= k) ? (double)below : (double)lo;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) below = max(below, __shfl_xor(below, o));
+        __syncthreads();
+        if (lane == 0) shm[wave][0] = below;
+        __syncthreads();
+        below = 0;
+        for (int w = 0; w < 16; ++w) below = max(below, shm[w][0]);
+        const double prev = (less >= k) ? (double)below : (double)med_lo;
         med = 0.5 * (med + prev);
     }
     if (tid == 0) {
-        out7[0] = 100.0 * (c1 / n); out7[1] = 100.0 * (c5 / n); out7[2] = 100.0 * (c10 / n);
-        out7[3] = floor(med); out7[4] = sum / n; out7[5] = isum / n; out7[6] = isum / n;
+        c1 = c5 = c10 = sum = 0; isum = 0;
+        for (int w = 0; w < 16; ++w) { c1 += shl[w][0]; c5 += shl[w][1]; c10 += shl[w][2]; sum += shl[w][3]; isum += shd[w]; }
+        const double dn = (double)n;
+        out7[0] = 100.0 * ((double)c1 / dn); out7[1] = 100.0 * ((double)c5 / dn); out7[2] = 100.0 * ((double)c10 / dn);
+        out7[3] = floor(med); out7[4] = (double)sum / dn; out7[5] = isum / dn; out7[6] = isum / dn;
         err[0] = 0;
     }
 }

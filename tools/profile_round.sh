@@ -1,0 +1,29 @@
+#!/bin/bash
+# Regenerates the evidence under profiles/ on a GPU box (run from the repo root, e.g. through gpurun):
+#   1. rocprofv3 --kernel-trace --stats of the default bench command  -> profiles/<tag>_bench_kernel_trace.txt
+#   2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE)             -> profiles/<tag>_bench_pmc_{fetch,write}.txt, <tag>_traffic.json
+#   3. the un-profiled bench line                                     -> profiles/<tag>_bench_line.json
+# Counter passes never combine --pmc with a trace domain (MI355X_MICROARCH.md; the pool refuses that combination).
+set -e
+TAG=${1:-r1}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT" "$ROOT/profiles"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- $BENCH > "$OUT/trace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- $BENCH > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- $BENCH > "$OUT/write.log" 2>&1
+cd "$ROOT"
+# summaries go to gpurun_out/ (the only directory gpurun copies back); `cp gpurun_out/prof_<tag>/summary/* profiles/` commits them
+S=$OUT/summary
+mkdir -p "$S"
+python3 tools/rocprof_summary.py "$OUT/trace" --out $S/${TAG}_bench_kernel_trace.txt
+python3 tools/rocprof_summary.py "$OUT/fetch" --out $S/${TAG}_bench_pmc_fetch.txt
+python3 tools/rocprof_summary.py "$OUT/write" --out $S/${TAG}_bench_pmc_write.txt
+python3 tools/make_traffic.py "$OUT/fetch" "$OUT/write" $S/${TAG}_traffic.json > /dev/null
+cp $S/${TAG}_traffic.json profiles/${TAG}_traffic.json          # bench.py reads roofline.traffic from here
+python3 tools/timeline.py "$OUT/trace" > $S/${TAG}_bench_timeline.txt || true
+cp "$OUT/trace/t_kernel_stats.csv" $S/${TAG}_bench_kernel_stats.csv
+python3 bench.py > $S/${TAG}_bench_line.json 2> "$OUT/bench.err"
+tail -c 700 $S/${TAG}_bench_line.json
