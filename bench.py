@@ -364,7 +364,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             sn, sv = (Nt, Nv) if float(Nt) * Nv <= 4.0e8 else (40000, 10000)       # ~10-20 s of host work
             line['cpu_baseline'] = cpu_baseline(args.workload, sn, sv, heads, d, args.seed, spec)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    # orderly teardown: captured graphs and their private pools go away while the HIP runtime is still up
+    import gc
+    graph = runner = state = res = None
+    gc.collect()
+    torch.cuda.synchronize()
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -121,15 +121,15 @@ def build_model(heads, d, device, frames=0, feat_dim=512, seed=1234, spec=None):
         name = 'LAFF'
     torch.manual_seed(seed)
     model = get_model(name, device, cfg).eval()
-    if not frames:
-        # Random-init towers put text and video in unrelated spaces (chance-level recall).  Tie the text tower to the
-        # video tower (feature k <-> feature k, same FC and attention parameters) so that the planted latent survives
-        # and R@K / MedR are informative about the arithmetic; the architecture and the work per pair are unchanged.
-        vis_mods = [getattr(model.vis_net.VisMutiTransformNet, n) for n in VID_FEATS]
-        txt_mods = [getattr(model.txt_net.transform_layer, e + '_transform') for e in model.txt_net.encoder_name_list]
-        for tm, vm in zip(txt_mods, vis_mods):
-            tm.load_state_dict(vm.state_dict())
-        model.txt_net.attention_layer.load_state_dict(model.vis_net.attention_layer.state_dict())
+    # Random-init towers put text and video in unrelated spaces (chance-level recall).  Tie the text tower to the
+    # video tower (feature k <-> feature k, same FC and attention parameters) so that the planted latent survives
+    # and R@K / MedR are informative about the arithmetic; the architecture and the work per pair are unchanged.
+    # (FrameLAFF: the video-level vector of feature k is the frame-attention output, a unit-norm weighted mean of frames.)
+    vis_mods = [getattr(model.vis_net if frames else model.vis_net.VisMutiTransformNet, n) for n in VID_FEATS]
+    txt_mods = [getattr(model.txt_net.transform_layer, e + '_transform') for e in model.txt_net.encoder_name_list]
+    for tm, vm in zip(txt_mods, vis_mods):
+        tm.load_state_dict(vm.state_dict())
+    model.txt_net.attention_layer.load_state_dict((model.vis_net.vis_attention_layer if frames else model.vis_net.attention_layer).state_dict())
     _randomise_bn(model, seed + 1)
     return model
 
@@ -153,8 +153,10 @@ def make_features(Nt, Nv, device, frames=0, feat_dim=512, seed=1234, noise=None,
     if frames:
         lens = torch.randint(max(1, frames // 4), frames + 1, (Nv,), generator=g, device=device, dtype=torch.int32)
         mask = (torch.arange(frames, device=device)[None, :] < lens[:, None]).to(torch.float32)
+        frame_P = []
         for n in VID_FEATS:
             P = randn(LATENT, feat_dim) / LATENT ** 0.5
+            frame_P.append(P)
             f = (zv @ P)[:, None, :] + noise * 2 * randn(Nv, frames, feat_dim)
             vis[n] = (f * mask[:, :, None]).contiguous()
         vis['mask_tensor'] = mask
@@ -171,8 +173,11 @@ def make_features(Nt, Nv, device, frames=0, feat_dim=512, seed=1234, noise=None,
             torch.randn(Nv, feat_dim, generator=g2, device=device)
     # text feature k of the tower (encoder order rnn, bow, w2v, CLIP) shares the projection of video feature k
     for i, n in enumerate(('rnn', 'bow', 'w2v', 'CLIP')):
-        P = Ps[i] if Ps else randn(LATENT, feat_dim) / LATENT ** 0.5
-        txt[TXT_KEY[n]] = zt @ P + noise * randn(Nt, feat_dim)
+        if frames:      # the matching video-level vector is unit-norm (frame attention output): same scale on the text side
+            x = zt @ frame_P[i] + noise * randn(Nt, feat_dim)
+            txt[TXT_KEY[n]] = x / x.norm(dim=1, keepdim=True)
+        else:
+            txt[TXT_KEY[n]] = zt @ Ps[i] + noise * randn(Nt, feat_dim)
     return vis, txt, gt.to(torch.int32), lens
 
 

@@ -44,3 +44,15 @@ def golden():
             cache[name] = Golden(name)
         return cache[name]
     return load
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _orderly_gpu_teardown():
+    """Drop captured HIP graphs / cached tensors and drain the device before the interpreter starts tearing modules down."""
+    yield
+    import gc
+    gc.collect()
+    if 'torch' in sys.modules:
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
