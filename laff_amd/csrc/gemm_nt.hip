@@ -18,10 +18,12 @@
 // The MFMA "A" operand is fed from C rows and "B" from R rows so that each lane ends up with 4 consecutive output
 // columns of one output row per accumulator quad.
 //
-// Two configurations are instantiated:
+// Three tile bodies are instantiated:
 //   Cfg128 : 2x2 waves of 64x64   -> 128x128 tile, 256 threads, 64 KiB LDS, 2 workgroups / CU   (fp32 FC, small problems)
 //   Cfg256 : 2x4 waves of 128x64  -> 256x256 tile, 512 threads, 128 KiB LDS, 1 workgroup / CU   (16-bit similarity:
 //            half the operand bytes per flop through the per-CU load path, 3/4 of the LDS reads per MFMA)
+//   CfgX3  : the Cfg256 wave layout on 32-element K-steps holding all four planes of a hi/lo split product, the three
+//            partial products interleaved per 16-element slice (gemm_tile_x3: split FC, fp16x3 / bf16x3 similarity)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
