@@ -82,6 +82,7 @@ int laff_ctx_create(int device, void* hip_stream, laff_ctx** out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(LAFF_E_UNSUPPORTED, "laff_ctx_create: device %d is %s; this library is built for gfx950 only", device,
                     prop.gcnArchName);
+    if (prop.multiProcessorCount > 0) laff::g_num_cus = prop.multiProcessorCount;
     laff_ctx* c = new laff_ctx();
     c->device = device;
     c->stream = static_cast<hipStream_t>(hip_stream);

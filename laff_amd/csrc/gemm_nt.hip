@@ -274,8 +274,21 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
 }
 
 // ---- one output tile ----------------------------------------------------------------------------------------------
+// linear tile id -> output origin: groups of 8 tile rows swept along c, so 8 R panels + 8 C panels live in L2 at a time
+template <typename CF>
+__device__ __forceinline__ void tile_origin(const GemmArgs& a, const int lin, int& r0, int& c0) {
+    const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
+    const int gsz_full = 8 * tiles_c;
+    const int grp = lin / gsz_full;
+    const int first_r = grp * 8;
+    const int gsz = min(tiles_r - first_r, 8);
+    const int in_grp = lin - grp * gsz_full;
+    r0 = (first_r + in_grp % gsz) * CF::TR;
+    c0 = (in_grp / gsz) * CF::TC;
+}
+
 template <int MODE, int STG, typename CF, int EPI>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char* smem) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const int c0, char* smem) {
     constexpr int ESZ = ModeTraits<MODE>::ESZ;
     constexpr int WM = CF::WM, WN = CF::WN, THREADS = CF::THREADS;
     constexpr bool GLDS = STG != 0;
@@ -285,16 +298,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int lin, char
     const int wr = wave / CF::WC, wc = wave % CF::WC;
     const int l31 = lane & 31, hh = lane >> 5;
 
-    // groups of 8 tile rows swept along c: 8 R panels + 8 C panels live in L2 at a time
-    const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
-    const int gsz_full = 8 * tiles_c;
-    const int grp = lin / gsz_full;
-    const int first_r = grp * 8;
-    const int gsz = min(tiles_r - first_r, 8);
-    const int in_grp = lin - grp * gsz_full;
-    const int tile_r = first_r + in_grp % gsz;
-    const int tile_c = in_grp / gsz;
-    const int r0 = tile_r * CF::TR, c0 = tile_c * CF::TC;
 
     const long ldRb = (long)a.ldR * ESZ, ldCb = (long)a.ldC * ESZ;
     const long Kb = (long)a.K * ESZ;
@@ -598,7 +601,7 @@ struct CfgX3 {
 };
 
 template <int MODE, int EPI>
-__device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int lin, char* smem) {
+__device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, const int c0, char* smem) {
     static_assert(MODE == GEMM_F16 || MODE == GEMM_BF16, "the split product runs on the 16-bit matrix pipe");
     using CF = CfgX3;
     constexpr int WM = CF::WM, WN = CF::WN, THREADS = CF::THREADS, RB = CF::ROWB, CPR = CF::CPR;
@@ -607,16 +610,6 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int lin, c
     const int wave = tid >> 6;
     const int wr = wave / CF::WC, wc = wave % CF::WC;
     const int l31 = lane & 31, hh = lane >> 5;
-
-    const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
-    const int gsz_full = 8 * tiles_c;
-    const int grp = lin / gsz_full;
-    const int first_r = grp * 8;
-    const int gsz = min(tiles_r - first_r, 8);
-    const int in_grp = lin - grp * gsz_full;
-    const int tile_r = first_r + in_grp % gsz;
-    const int tile_c = in_grp / gsz;
-    const int r0 = tile_r * CF::TR, c0 = tile_c * CF::TC;
 
     const long ldRb = (long)a.ldR * 2, ldCb = (long)a.ldC * 2;
     const int nkt = (int)(((long)a.K * 2) / RB);                  // K bytes are a multiple of 128 on this path
@@ -775,23 +768,41 @@ template <int MODE>
 __global__ __launch_bounds__(CfgX3::THREADS, CfgX3::WPS) void gemm_nt_x3_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_r = (a.nR + CfgX3::TR - 1) / CfgX3::TR, tiles_c = (a.nC + CfgX3::TC - 1) / CfgX3::TC;
-    gemm_tile_x3<MODE, EPI_SIM>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), smem);
+    int r0, c0;
+    tile_origin<CfgX3>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), r0, c0);
+    gemm_tile_x3<MODE, EPI_SIM>(a, r0, c0, smem);
 }
 
 template <int MODE>
 __global__ __launch_bounds__(CfgX3::THREADS, CfgX3::WPS) void gemm_nt_x3_grouped_kernel(GroupedGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lin = xcd_remap(blockIdx.x, g.tile_start[g.count]);
+    // Blocks [0, nbig) run 256x256 tiles.  The big tiles that would form a sparsely filled LAST round (e.g. 40 of 256 CUs busy
+    // for a whole tile time: 12 % of this launch at C4) are cut into four 128x128 tiles each, run by blocks [nbig, grid) on the
+    // Cfg128 body (waves 4..7 of those blocks retire at once): the tail round then lasts a quarter as long.
+    const bool big = (int)blockIdx.x < g.nbig;
+    const int lin = big ? xcd_remap(blockIdx.x, g.nbig) : g.nbig + (((int)blockIdx.x - g.nbig) >> 2);
     int p = 0;
     while (p + 1 < g.count && lin >= g.tile_start[p + 1]) ++p;     // wave-uniform scalar search
-    gemm_tile_x3<MODE, EPI_FC>(g.p[p], lin - g.tile_start[p], smem);
+    int r0, c0;
+    tile_origin<CfgX3>(g.p[p], lin - g.tile_start[p], r0, c0);
+    if (big) {
+        gemm_tile_x3<MODE, EPI_FC>(g.p[p], r0, c0, smem);
+    } else {
+        const int q = ((int)blockIdx.x - g.nbig) & 3;
+        r0 += (q >> 1) * Cfg128::TR;
+        c0 += (q & 1) * Cfg128::TC;
+        if (r0 >= g.p[p].nR || c0 >= g.p[p].nC || threadIdx.x >= Cfg128::THREADS) return;
+        gemm_tile<MODE, 2, Cfg128, EPI_FC>(g.p[p], r0, c0, smem);
+    }
 }
 
 template <int MODE, int STG, typename CF>
 __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
-    gemm_tile<MODE, STG, CF, EPI_SIM>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), smem);
+    int r0, c0;
+    tile_origin<CF>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), r0, c0);
+    gemm_tile<MODE, STG, CF, EPI_SIM>(a, r0, c0, smem);
 }
 
 // several independent problems (the FC projections of all fused features) in ONE launch: fills the chip where a
@@ -802,7 +813,9 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_grouped_kernel(G
     const int lin = xcd_remap(blockIdx.x, g.tile_start[g.count]);
     int p = 0;
     while (p + 1 < g.count && lin >= g.tile_start[p + 1]) ++p;     // wave-uniform scalar search
-    gemm_tile<MODE, STG, CF, EPI_FC>(g.p[p], lin - g.tile_start[p], smem);
+    int r0, c0;
+    tile_origin<CF>(g.p[p], lin - g.tile_start[p], r0, c0);
+    gemm_tile<MODE, STG, CF, EPI_FC>(g.p[p], r0, c0, smem);
 }
 
 template <typename K>
@@ -838,6 +851,7 @@ int staging_kind(const GemmArgs& a, int esz, bool aligned) {
 template <int MODE>
 static hipError_t launch_x3(const GemmArgs& a, hipStream_t st);
 
+int g_num_cus = 256;       // set from the device properties when a ctx is created
 int g_gemm_variant = 0;   // tuning knob LAFF_GEMM_VARIANT: 128 / 256 force the tile configuration of the 16-bit GEMM (256 also
                           // keeps split products in the concatenated form); 3 forces the big tiles incl. the interleaved x3 tile
 
@@ -896,13 +910,18 @@ static hipError_t launch_grouped_x3(GroupedGemmArgs& g, hipStream_t st) {
     }
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
     g.tile_start[g.count] = (int)nb;
+    // tail split: the big tiles of a last round that would fill at most 3/4 of the CUs become 4 small tiles each
+    const long rem = nb % g_num_cus;
+    g.nbig = (int)nb;
+    if (g_gemm_variant != 4 && nb > g_num_cus && rem > 0 && rem * 4 <= 3L * g_num_cus) g.nbig = (int)(nb - rem);
+    const long grid = g.nbig + 4L * (nb - g.nbig);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = set_smem(gemm_nt_x3_grouped_kernel<GEMM_F16>, CfgX3::SMEM);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_x3_grouped_kernel<GEMM_F16>), dim3((unsigned)nb), dim3(CfgX3::THREADS), CfgX3::SMEM, st, g);
+    hipLaunchKernelGGL((gemm_nt_x3_grouped_kernel<GEMM_F16>), dim3((unsigned)grid), dim3(CfgX3::THREADS), CfgX3::SMEM, st, g);
     return hipGetLastError();
 }
 

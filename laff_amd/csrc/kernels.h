@@ -37,6 +37,7 @@ struct GemmArgs {
 constexpr int MAX_GROUP = 8;
 struct GroupedGemmArgs {
     int count;
+    int nbig;             // x3 grouped kernel: blocks [0, nbig) run big tiles, the rest quarter tiles of the remaining ones
     int tile_start[MAX_GROUP + 1];
     GemmArgs p[MAX_GROUP];
 };
@@ -46,6 +47,7 @@ hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int staging, hipStream
 hipError_t launch_gemm_nt_grouped_f16(GroupedGemmArgs& g, hipStream_t st);   // fast staging only (packed operands)
 int staging_kind(const GemmArgs& a, int esz, bool aligned);
 extern int g_gemm_variant;
+extern int g_num_cus;
 
 constexpr int MAX_L = 8;
 struct FuseArgs {

@@ -254,3 +254,24 @@ def test_c1_test3k_shapes_sparse_bow_equals_dense_and_oracle_sample():
     for a, b in zip(res.metrics[:3], strict.metrics[:3]):
         assert abs(a - b) <= 0.02
     assert res.metrics[0] > 5.0                                  # far above chance (0.03 %)
+
+
+def test_split_fc_with_tail_split_matches_fp32_path():
+    """C4's eight projections in one grouped launch: 1,576 big tiles = 6 full rounds of 256 CUs + 40, whose last 40 tiles run as
+    160 quarter tiles on the small tile body.  Same result as the fp32-MFMA path problem by problem."""
+    from laff_amd import ops
+    torch.manual_seed(0)
+    rows = [40000] * 4 + [10000] * 4
+    W = [torch.randn(512, 512, device=DEV) / 22 for _ in rows]
+    Ws = [ops.split_rows(w) for w in W]
+    X = [torch.randn(n, 512, device=DEV) for n in rows]
+    X[5][7] *= 3e4                                   # a huge and a tiny row: the per-row scales must carry them
+    X[1][11] *= 1e-6
+    b = torch.randn(512, device=DEV) * 0.1
+    sc = torch.rand(512, device=DEV) + 0.5
+    sh = torch.randn(512, device=DEV) * 0.1
+    probs = [dict(x=X[i], weight_split=Ws[i], bias=b, bn_scale=sc, bn_shift=sh, activation='tanh') for i in range(8)]
+    outs = ops.fc_act_bn_split_grouped(probs)
+    for i in (0, 3, 4, 5, 7):
+        ref = ops.fc_act_bn(X[i], W[i], b, sc, sh, 'tanh')
+        assert float((outs[i] - ref).abs().max()) <= 2e-5
