@@ -182,13 +182,15 @@ def main():
     force_dist = args.force_dist and dist.is_initialized()
     distributed = world > 1 or force_dist
 
-    def step(timed, async_metrics=False, runner=None, state=None):
+    pins = [metrics_pinned, torch.zeros(8, dtype=torch.float64).pin_memory()]
+
+    def step(timed, async_metrics=False, runner=None, state=None, slot=0):
         timer.enabled = timed
         prof.enabled = timed
         timer.start()
         return evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer,
-                                metrics_out=metrics_pinned if async_metrics else None, runner=runner, state=state,
-                                force_collectives=force_dist)
+                                metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
+                                force_collectives=force_dist, finish_tag=str(slot))
 
     # Launch modes of the timed region (host issue of ~15 launches costs 0.3-0.4 ms per step, as much as the GPU work of a
     # 1/4 shard, and sits on the critical path because every step ends with a host sync on the 7 metrics):
@@ -196,7 +198,7 @@ def main():
     #   N > 1      : one captured graph per LOCAL phase (laff_amd.dist.GraphRunner), the three RCCL collectives eager
     #                between them -- nothing RCCL-related is ever captured;
     #   --no-graph : eager launches.
-    graph, graphs, pins, runner, state = None, [], [], None, {}
+    graph, graphs, runner, state = None, [], None, {}
     for _ in range(max(1, args.warmup)):
         res = step(False)
     torch.cuda.synchronize()
@@ -205,13 +207,14 @@ def main():
             if distributed:
                 from laff_amd.dist import GraphRunner
                 runner = GraphRunner()
-                res = step(False, async_metrics=True, runner=runner, state=state)      # captures + runs every phase once
-                torch.cuda.synchronize()
+                for slot in (0, 1):      # captures + runs every phase once (the 'finish' phase once per metrics buffer)
+                    res = step(False, async_metrics=True, runner=runner, state=state, slot=slot)
+                    torch.cuda.synchronize()
             else:
                 # two captures of the same step with their own output buffers: step k+1 is enqueued while the host still
                 # reads the 7 metrics of step k, so the GPU never idles between steps (a single graph with a host sync after
                 # every replay left a 30 us hole per step = 2.4 %)
-                graphs, pins = [], [metrics_pinned, torch.zeros(8, dtype=torch.float64).pin_memory()]
+                graphs = []
                 for gi in range(2):
                     gph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gph):
@@ -225,7 +228,9 @@ def main():
             graph, runner = None, None
             torch.cuda.synchronize()
             res = step(False)
-    launch_mode = 'HIP graph replay, step k+1 enqueued while the host reads the metrics of step k' if graph is not None else ('per-phase HIP graphs + eager RCCL' if runner is not None else 'eager')
+    launch_mode = ('HIP graph replay, step k+1 enqueued while the host reads the metrics of step k' if graph is not None else
+                   ('per-phase HIP graphs + eager RCCL, step k+1 issued while the host reads the metrics of step k'
+                    if runner is not None else 'eager'))
 
     def timed_step():
         if graph is not None:
@@ -242,13 +247,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    if graph is not None:
+    if graph is not None or runner is not None:
+        # two steps in flight at most: step k is issued, then the host waits for step k-1 and reads ITS metrics buffer
         events = [torch.cuda.Event(), torch.cuda.Event()]
         seen = []
         for k in range(args.steps):
-            graphs[k % 2].replay()
+            if graph is not None:
+                graphs[k % 2].replay()
+            else:
+                res = step(False, async_metrics=True, runner=runner, state=state, slot=k % 2)
             events[k % 2].record()
-            if k:                                        # step k-1: its metrics are on the host before step k+1 may reuse the buffer
+            if k:
                 events[(k - 1) % 2].synchronize()
                 seen.append(float(pins[(k - 1) % 2][0]))
         events[(args.steps - 1) % 2].synchronize()
@@ -269,7 +278,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if graph is not None or runner is not None:
-        final_metrics = tuple((pins[(args.steps - 1) % 2] if graph is not None else metrics_pinned)[:7].tolist())
+        final_metrics = tuple(pins[(args.steps - 1) % 2][:7].tolist())
         # per-kernel durations: the same kernels on the same data, launched eagerly with events around each launch
         # (every rank runs the same number of steps: the collectives stay matched)
         for _ in range(args.profile_steps):

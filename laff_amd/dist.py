@@ -133,12 +133,15 @@ def _eager(name, fn):
 
 
 def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
-                     timer=None, want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False):
+                     timer=None, want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False,
+                     finish_tag=''):
     """One pass of the hot path on this rank's shards.  gt: (Nt,) int32 GLOBAL video column of every text (replicated).
 
     runner: None (eager) or a GraphRunner; state: dict that persists across steps (static collective buffers) -- required
     with a GraphRunner.  force_collectives runs the collectives even on a 1-rank group (used to exercise the N > 1 code
-    path on a single GPU).  Returns dict(S_local (Nt, v1-v0), col0, ranks (Nt,), metrics)."""
+    path on a single GPU).  finish_tag names the captured 'finish' phase: callers that alternate between several metrics_out
+    buffers (to keep a step in flight while the host reads the previous one) pass a different tag per buffer.
+    Returns dict(S_local (Nt, v1-v0), col0, ranks (Nt,), metrics)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     comm = world > 1 or (force_collectives and dist.is_initialized())
@@ -217,7 +220,7 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
             if metrics_out is not None:
                 compute.metrics_async(ranks, metrics_out)     # no host sync: the caller reads metrics_out after one
             return ranks
-        ranks = run('finish', finish)
+        ranks = run('finish' + finish_tag, finish)
         mark('rank')
         metrics = None
         if metrics_out is None and want_metrics:
