@@ -177,7 +177,8 @@ int laff_pack_rows(laff_ctx* ctx, const float* E, int N, int H, int d, int lde, 
  * S[Nt,Nv] = scale * T[Nt,K] . V[Nv,K]^T on operands produced by laff_pack_rows (K = H*d, scale = 1/(H*prescale^2)).
  * S may be NULL when only ranks are wanted.  If gt_col != NULL the epilogue also accumulates
  *   count[t] += #{ v : v + col0 != gt_col[t] and S[t,v] > s_gt[t] }   (count must be zeroed by the caller)
- * which is the argsort/label loop of predictor.py:232-244 in count form.  K % 64 == 0 (16-bit), K % 32 == 0 (fp32). */
+ * which is the argsort/label loop of predictor.py:232-244 in count form.  Any K (even for 16-bit
+ * operands); K bytes a multiple of 128 takes the fast direct-to-LDS path, other sizes the generic staging paths. */
 int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale,
                   int precision, float* S, int lds, const int* gt_col, int col0, const float* s_gt,
                   int* count);

@@ -422,8 +422,9 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
     if (Nt == 0 || Nv == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!T || !V) return fail(LAFF_E_ARG, "laff_sim_gemm: null T/V");
     if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "laff_sim_gemm: bad precision %d", precision);
-    const int kmul = precision == LAFF_PREC_FP32 ? 32 : 64;
-    if (Nt < 0 || Nv < 0 || K < kmul || (K % kmul)) return fail(LAFF_E_SHAPE, "laff_sim_gemm: need K%%%d==0 (Nt=%d Nv=%d K=%d)", kmul, Nt, Nv, K);
+    const int esz = precision == LAFF_PREC_FP32 ? 4 : 2;
+    if (Nt < 0 || Nv < 0 || K < 1 || ((long)K * esz) % 4)
+        return fail(LAFF_E_SHAPE, "laff_sim_gemm: K must be positive (and even for 16-bit operands) (Nt=%d Nv=%d K=%d)", Nt, Nv, K);
     if (!S && !gt_col) return fail(LAFF_E_ARG, "laff_sim_gemm: nothing to produce (S and gt_col both null)");
     if (S && lds < Nv) return fail(LAFF_E_SHAPE, "laff_sim_gemm: lds=%d < Nv=%d", lds, Nv);
     if (gt_col && (!s_gt || !count)) return fail(LAFF_E_ARG, "laff_sim_gemm: gt_col needs s_gt and count");
@@ -448,7 +449,9 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
     if (precision == LAFF_PREC_FP16 || precision == LAFF_PREC_FP16X3) mode = laff::GEMM_F16;
     if (precision == LAFF_PREC_BF16 || precision == LAFF_PREC_BF16X3) mode = laff::GEMM_BF16;
     DeviceGuard g(ctx->device);
-    HIP_TRY(laff::launch_gemm_nt(a, mode, true, ctx->stream));
+    // rows of K elements: 16-byte aligned rows take the direct-to-LDS paths (K bytes a multiple of 128: the fast one),
+    // anything else is staged through registers with element-wise K bounds
+    HIP_TRY(laff::launch_gemm_nt(a, mode, ((long)K * esz) % 16 == 0, ctx->stream));
     return LAFF_OK;
 }
 
@@ -505,7 +508,7 @@ int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv,
     if (Nt == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!T || !V || !gt_col || !s_gt) return fail(LAFF_E_ARG, "laff_row_dot_gt: null argument");
     if (precision < LAFF_PREC_FP16 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_UNSUPPORTED, "laff_row_dot_gt: 16-bit precisions only (got %d)", precision);
-    if (Nt < 0 || Nv < 0 || K < 8 || (K & 7)) return fail(LAFF_E_SHAPE, "laff_row_dot_gt: need K%%8==0 (K=%d)", K);
+    if (Nt < 0 || Nv < 0 || K < 2 || (K & 1)) return fail(LAFF_E_SHAPE, "laff_row_dot_gt: K must be positive and even (K=%d)", K);
     if (!aligned16(T) || !aligned16(V)) return fail(LAFF_E_ALIGN, "laff_row_dot_gt: operands must be 16-byte aligned");
     if (Nt == 0) return LAFF_OK;
     const int bf16 = (precision == LAFF_PREC_BF16 || precision == LAFF_PREC_BF16X3);

@@ -121,6 +121,12 @@ __global__ __launch_bounds__(256) void row_dot_gt_kernel(const uint16_t* __restr
     const uint16_t* vr = V + (long)c * K;
     const long pT = (long)Nt * K, pV = (long)Nv * K;
     float acc = 0.f;
+    if (K & 7) {                                   // rows are not 16-byte multiples: element-wise
+        for (int k = lane; k < K; k += 64) {
+            if (x3) acc += cvt(tr[pT + k]) * cvt(vr[k]) + cvt(tr[k]) * cvt(vr[pV + k]);
+            acc = fmaf(cvt(tr[k]), cvt(vr[k]), acc);
+        }
+    } else
     for (int k = lane * 8; k < K; k += 512) {
         uint4 a = *(const uint4*)(tr + k), b = *(const uint4*)(vr + k);
         const uint16_t* pa = (const uint16_t*)&a;
@@ -152,39 +158,6 @@ hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K
 
 // evaluation.eval (/root/reference/evaluation.py:92-109) for single-GT rows, on the device: one 1024-thread block.
 // out7 = r1, r5, r10, medr, meanr, mir, mAP (= mir).  err[0] != 0 if a rank < 1 was seen.
-__device__ __forceinline__ double block_sum(double v, double* sh) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double t = 0;
-    for (int i = 0; i < 16; ++i) t += sh[i];
-    return t;
-}
-__device__ __forceinline__ int block_max(int v, double* sh) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = (double)v;
-    __syncthreads();
-    double t = sh[0];
-    for (int i = 1; i < 16; ++i) t = fmax(t, sh[i]);
-    return (int)t;
-}
-
-__device__ __forceinline__ int block_sum_int(int v, int* sh) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    int t = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += sh[i];
-    return t;
-}
-
 // The median is an order statistic of positive integers: MSB-first radix select with 8-bit digits, starting at the top
 // non-zero byte of the largest rank (two passes for ranks < 65536).  The digit histogram lives in LDS with every bin
 // REPLICATED 32 times (replica = lane & 31, row pitch 33 words): retrieval ranks pile up on a few values (41 % are rank 1
