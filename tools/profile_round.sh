@@ -25,5 +25,6 @@ python3 tools/make_traffic.py "$OUT/fetch" "$OUT/write" $S/${TAG}_traffic.json >
 cp $S/${TAG}_traffic.json profiles/${TAG}_traffic.json          # bench.py reads roofline.traffic from here
 python3 tools/timeline.py "$OUT/trace" > $S/${TAG}_bench_timeline.txt || true
 cp "$OUT/trace/t_kernel_stats.csv" $S/${TAG}_bench_kernel_stats.csv
+grep '"metric"' "$OUT/trace.log" | tail -1 > $S/${TAG}_bench_line_under_rocprof.json || true   # the bench's own HIP-event durations in the traced run
 python3 bench.py > $S/${TAG}_bench_line.json 2> "$OUT/bench.err"
 tail -c 700 $S/${TAG}_bench_line.json

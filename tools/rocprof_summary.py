@@ -29,16 +29,18 @@ def main():
         agg = collections.OrderedDict()
         for r in rows:
             dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1000.0
-            a = agg.setdefault(r['Kernel_Name'], [0, 0.0, 1e30, 0.0, r.get('VGPR_Count', ''), r.get('LDS_Block_Size', ''), r.get('Grid_Size', '')])
+            a = agg.setdefault(r['Kernel_Name'], [0, 0.0, 1e30, 0.0, r.get('VGPR_Count', ''), r.get('LDS_Block_Size', ''), r.get('Grid_Size', ''), []])
+            a[7].append(dur)
             a[0] += 1
             a[1] += dur
             a[2] = min(a[2], dur)
             a[3] = max(a[3], dur)
         tot = sum(a[1] for a in agg.values())
         print('# kernel trace: %s  (total GPU kernel time %.1f us)' % (os.path.basename(f), tot), file=out)
-        print('%-98s %6s %10s %10s %10s %11s %6s %5s %7s' % ('kernel', 'calls', 'avg_us', 'min_us', 'max_us', 'total_us', 'pct', 'vgpr', 'lds'), file=out)
+        print('%-98s %6s %10s %10s %10s %10s %11s %6s %5s %7s' % ('kernel', 'calls', 'avg_us', 'median_us', 'min_us', 'max_us', 'total_us', 'pct', 'vgpr', 'lds'), file=out)
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print('%-98s %6d %10.2f %10.2f %10.2f %11.1f %5.1f%% %5s %7s' % (short(k), a[0], a[1] / a[0], a[2], a[3], a[1], 100 * a[1] / tot, a[4], a[5]), file=out)
+            med = sorted(a[7])[len(a[7]) // 2]
+            print('%-98s %6d %10.2f %10.2f %10.2f %10.2f %11.1f %5.1f%% %5s %7s' % (short(k), a[0], a[1] / a[0], med, a[2], a[3], a[1], 100 * a[1] / tot, a[4], a[5]), file=out)
         print(file=out)
     for f in sorted(glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)):
         rows = list(csv.DictReader(open(f)))
