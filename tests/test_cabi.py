@@ -53,3 +53,25 @@ def test_cpu_tensors_are_refused():
     from laff_amd import ops
     with pytest.raises(RuntimeError, match='no CPU path'):
         ops.fc_act_bn(torch.zeros(4, 8), torch.zeros(16, 8))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No CPU fallback: with the shared library absent the first op raises (checked in a child process)."""
+    import subprocess
+    import sys
+    code = ("import os, sys; os.environ['LAFF_HIP_LIB'] = %r; sys.path.insert(0, %r); "
+            "from laff_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept RuntimeError as e:\n    assert 'no CPU fallback' in str(e); print('RAISED')\n"
+            % (str(tmp_path / 'nope.so'), ROOT))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert 'RAISED' in out.stdout, out.stderr
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under laff_amd/ may import or execute it (tier rule 3)."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, 'laff_amd', '**', '*.py'), recursive=True):
+        src = open(f).read()
+        assert 'import oracle' not in src and 'from oracle' not in src and 'laff_oracle' not in src, f
+    for f in glob.glob(os.path.join(ROOT, 'laff_amd', 'csrc', '*')):
+        assert 'oracle' not in open(f).read().lower(), f
