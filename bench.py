@@ -311,6 +311,7 @@ def main():
             'fc_act_bn': ('mfma', 2.0 * fc_macs * (3 if args.fc_precision == 'fp16x3' else 1),
                           MFMA_PEAK_TFLOPS['f16' if args.fc_precision == 'fp16x3' else 'f32'], 1e12, 'TFLOP/s'),
             'split_rows': ('hbm', (4.0 + 4.0) * (nvl * sum(fc_v) + ntl * sum(fc_t)), HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'row_scales': ('hbm', 4.0 * (nvl * sum(fc_v) + ntl * sum(fc_t)), HBM_PEAK_GBS, 1e9, 'GB/s'),
             'fuse': ('hbm', 4.0 * K * (nvl * (Lv + 1 - (1 if raw_v else 0)) + ntl * (Lt + 1 - (1 if raw_t else 0)))
                      + 4.0 * (nvl * raw_v + ntl * raw_t), HBM_PEAK_GBS, 1e9, 'GB/s'),
             'fc_gather': ('hbm', 4.0 * K * (sum(gather_dims) + ntl) + 8.0 * sparse_nnz, HBM_PEAK_GBS, 1e9, 'GB/s'),

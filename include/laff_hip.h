@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 5
+#define LAFF_ABI_VERSION 6
 
 enum {
     LAFF_OK = 0,
@@ -107,6 +107,22 @@ typedef struct {
     float* Y; int ldy;
 } laff_fc_split_problem;
 int laff_fc_act_bn_split_grouped(laff_ctx* ctx, const laff_fc_split_problem* problems /*host array*/, int count);
+
+/* The same projection with the INPUT split fused into the GEMM: X stays fp32 in HBM, only its per-row power-of-two scales are
+ * computed beforehand (laff_row_scales_grouped: one read of X, N floats out; same scales as laff_split_rows) and the kernel
+ * forms the fp16 hi / lo planes on the way into LDS -- laff_split_rows' 2 x N x Kp fp16 planes are never written or re-read.
+ * Results are bit-identical to laff_split_rows + laff_fc_act_bn_split_grouped on 256x256 tiles.
+ * Needs Dk % 32 == 0, ldx % 4 == 0 and 16-byte aligned X rows; W is split once with laff_split_rows as before. */
+int laff_row_scales_grouped(laff_ctx* ctx, int count, const float* const* X, const int* N, const int* K, const int* ldx,
+                            float* const* rscale);
+typedef struct {
+    const float* X; int ldx; const float* x_rscale; int N, Dk;  /* fp32 input + laff_row_scales_grouped(X) */
+    const void* Ws; const float* w_rscale;                      /* laff_split_rows(W[D,Dk]) */
+    const float* bias; const float* bn_scale; const float* bn_shift;
+    int D, act;
+    float* Y; int ldy;
+} laff_fc_fused_problem;
+int laff_fc_act_bn_fused_grouped(laff_ctx* ctx, const laff_fc_fused_problem* problems /*host array*/, int count);
 
 /* a1 for a SPARSE input feature (bag-of-words, model/model.py:399-416): X given as CSR (indptr[N+1], indices[nnz],
  * values[nnz] or NULL = all ones) over Dk columns; Wt = W^T [Dk, ldwt >= D] so that one vocabulary entry is one contiguous

@@ -329,6 +329,61 @@ int laff_fc_act_bn_split_grouped(laff_ctx* ctx, const laff_fc_split_problem* pro
     return LAFF_OK;
 }
 
+int laff_row_scales_grouped(laff_ctx* ctx, int count, const float* const* X, const int* N, const int* K, const int* ldx,
+                            float* const* rscale) {
+    CHECK_CTX(ctx);
+    if (count < 0 || (count && (!X || !N || !K || !ldx || !rscale))) return fail(LAFF_E_ARG, "laff_row_scales_grouped: bad argument list");
+    DeviceGuard g(ctx->device);
+    for (int i0 = 0; i0 < count; i0 += 8) {
+        const int c = count - i0 < 8 ? count - i0 : 8;
+        void* none[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        for (int i = i0; i < i0 + c; ++i) {
+            if (N[i] == 0) continue;
+            if (!X[i] || !rscale[i]) return fail(LAFF_E_ARG, "laff_row_scales_grouped: matrix %d has a null pointer", i);
+            if (N[i] < 0 || K[i] < 1 || ldx[i] < K[i]) return fail(LAFF_E_SHAPE, "laff_row_scales_grouped: matrix %d bad shape", i);
+        }
+        HIP_TRY(laff::launch_split_rows_grouped(c, X + i0, N + i0, K + i0, ldx + i0, none, rscale + i0, ctx->stream));
+    }
+    return LAFF_OK;
+}
+
+int laff_fc_act_bn_fused_grouped(laff_ctx* ctx, const laff_fc_fused_problem* problems, int count) {
+    CHECK_CTX(ctx);
+    if (!problems || count < 0) return fail(LAFF_E_ARG, "laff_fc_act_bn_fused_grouped: bad problem list");
+    DeviceGuard g(ctx->device);
+    laff::GroupedGemmArgs ga{};
+    for (int i = 0; i < count; ++i) {
+        const laff_fc_fused_problem& q = problems[i];
+        if (q.N == 0) continue;
+        if (!q.X || !q.Ws || !q.x_rscale || !q.w_rscale || !q.Y) return fail(LAFF_E_ARG, "laff_fc_act_bn_fused_grouped: problem %d has a null operand", i);
+        if (q.N < 0 || q.Dk < 32 || (q.Dk & 31) || q.D < 1 || q.ldy < q.D || q.ldx < q.Dk || (q.ldx & 3))
+            return fail(LAFF_E_SHAPE, "laff_fc_act_bn_fused_grouped: problem %d: need Dk %% 32 == 0, ldx %% 4 == 0 (N=%d Dk=%d D=%d ldx=%d ldy=%d)",
+                        i, q.N, q.Dk, q.D, q.ldx, q.ldy);
+        if (q.act < LAFF_ACT_NONE || q.act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fc_act_bn_fused_grouped: bad act %d", q.act);
+        if ((q.bn_scale == nullptr) != (q.bn_shift == nullptr)) return fail(LAFF_E_ARG, "laff_fc_act_bn_fused_grouped: bn_scale/bn_shift must come together");
+        if (!aligned16(q.X) || !aligned16(q.Ws) || (q.bias && !aligned16(q.bias)) || (q.bn_scale && (!aligned16(q.bn_scale) || !aligned16(q.bn_shift))))
+            return fail(LAFF_E_ALIGN, "laff_fc_act_bn_fused_grouped: problem %d: 16-byte alignment", i);
+        const int Kp = (q.Dk + 63) / 64 * 64;
+        if ((long long)q.N * q.ldx * 4 >= (1ll << 32) || (long long)q.D * Kp * 4 >= (1ll << 32))
+            return fail(LAFF_E_UNSUPPORTED, "laff_fc_act_bn_fused_grouped: problem %d: operand exceeds 4 GiB", i);
+        laff::GemmArgs a{};
+        a.Rf = q.X; a.ldRf = q.ldx; a.R = nullptr; a.ldR = 0;
+        a.C = q.Ws; a.nR = q.N; a.nC = q.D; a.K = q.Dk; a.ldC = Kp;
+        a.nseg = 3;
+        a.segC[0] = 0; a.segC[1] = (long)q.D * Kp * 2; a.segC[2] = 0;
+        a.out = q.Y; a.ldo = q.ldy; a.scale = 1.0f;
+        a.row_scale = q.x_rscale; a.col_scale = q.w_rscale;
+        a.bias = q.bias; a.bn_scale = q.bn_scale; a.bn_shift = q.bn_shift; a.act = q.act;
+        ga.p[ga.count++] = a;
+        if (ga.count == laff::MAX_GROUP) {
+            HIP_TRY(laff::launch_gemm_nt_x3_fused_grouped(ga, ctx->stream));
+            ga.count = 0;
+        }
+    }
+    if (ga.count) HIP_TRY(laff::launch_gemm_nt_x3_fused_grouped(ga, ctx->stream));
+    return LAFF_OK;
+}
+
 int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
                      const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale);
 

@@ -520,6 +520,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs g) {
         if (m > 0.f && m < INFINITY) e = ilogbf(m);
         const float s = ldexpf(1.0f, 9 - e);
         if (lane == 0) g.rscale[p][n] = ldexpf(1.0f, e - 9);
+        if (!g.out[p]) return;                                   // scales only (laff_row_scales_grouped)
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = j * 256 + lane * 4;
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs g) {
         if (m > 0.f && m < INFINITY) e = ilogbf(m);
         const float s = ldexpf(1.0f, 9 - e);
         if (lane == 0) g.rscale[p][n] = ldexpf(1.0f, e - 9);
+        if (!g.out[p]) return;
         for (int c = lane * 4; c < Kp; c += 256) {       // Kp % 64 == 0, rows of the packed operand are 128-byte aligned
             h4 h, l;
 #pragma unroll

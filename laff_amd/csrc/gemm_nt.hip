@@ -600,7 +600,12 @@ struct CfgX3 {
     static_assert(THREADS / 64 * 32 * PITCH * 4 <= SMEM, "epilogue slabs must fit in the operand ring");
 };
 
-template <int MODE, int EPI>
+// RF32: the row operand is given as fp32 (a.Rf, leading dimension a.ldRf, per-row power-of-two scales a.row_scale from
+// laff_row_scales) and split into its fp16 hi / lo planes HERE, on its way into LDS -- the planes are never written to HBM
+// (laff_split_rows writes 410 MB and the GEMM reads them back at C4).  16 values per thread and K-step: two 32-byte global
+// loads right after the barrier, converted (same arithmetic as split_rows_kernel: bit-identical planes) and stored with four
+// ds_write_b128 one K-step later, between two MFMA groups.
+template <int MODE, int EPI, bool RF32 = false>
 __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, const int c0, char* smem) {
     static_assert(MODE == GEMM_F16 || MODE == GEMM_BF16, "the split product runs on the 16-bit matrix pipe");
     using CF = CfgX3;
@@ -612,7 +617,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     const int l31 = lane & 31, hh = lane >> 5;
 
     const long ldRb = (long)a.ldR * 2, ldCb = (long)a.ldC * 2;
-    const int nkt = (int)(((long)a.K * 2) / RB);                  // K bytes are a multiple of 128 on this path
+    const int nkt = (int)(((long)a.K * 2) / RB);                  // K bytes are a multiple of 64 on this path (128 unless RF32)
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -631,6 +636,23 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
         offR[sub] = (unsigned)min(r0 + row, a.nR - 1) * (unsigned)ldRb + (unsigned)ch * 16u;
         offC[sub] = (unsigned)min(c0 + row, a.nC - 1) * (unsigned)ldCb + (unsigned)ch * 16u;
     }
+    // RF32: unit u = sub*THREADS + tid covers 8 consecutive K values (32 source bytes) of row u/4
+    unsigned xoff[2] = {0, 0}, xdst[2] = {0, 0};
+    float xscale[2] = {1.0f, 1.0f};
+    u32x4 xs[2][2];
+    unsigned long long fX = 0;
+    unsigned x_sa = 0;                                            // LDS slot the staged values go to
+    bool conv_pending = false;
+    if constexpr (RF32) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int p = sub * THREADS + tid, row = p / CPR, ch = p % CPR;
+            const int gr = min(r0 + row, a.nR - 1);
+            xoff[sub] = (unsigned)gr * (unsigned)(a.ldRf * 4) + (unsigned)ch * 32u;
+            xdst[sub] = (unsigned)row * RB + (unsigned)(ch ^ ((row >> 2) & 3)) * 16u;
+            xscale[sub] = 1.0f / a.row_scale[gr];                 // exact: the scales are powers of two
+        }
+    }
     // planes: segments of the concatenated formulation are (R_lo, C_hi), (R_hi, C_lo), (R_hi, C_hi)
     const unsigned long long bRhi = (unsigned long long)((const char*)a.R + a.segR[1]), bRlo = (unsigned long long)((const char*)a.R + a.segR[0]);
     const unsigned long long bChi = (unsigned long long)((const char*)a.C + a.segC[0]), bClo = (unsigned long long)((const char*)a.C + a.segC[1]);
@@ -642,10 +664,42 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
         const unsigned long long kb = (unsigned long long)((long)kt * RB);
         fRhi = uniform64(bRhi + kb); fRlo = uniform64(bRlo + kb); fChi = uniform64(bChi + kb); fClo = uniform64(bClo + kb);
         fill_sa = lds0 + (unsigned)buf * CF::STAGEB;
+        if constexpr (RF32) fX = uniform64((unsigned long long)((const char*)a.Rf) + (unsigned long long)((long)kt * (RB * 2)));
+    };
+    auto xload = [&]() {                         // 4 x global_load_dwordx4 (saddr form), no wait
+        x_sa = fill_sa;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+                         : "=&v"(xs[sub][0]), "=&v"(xs[sub][1])
+                         : "v"(xoff[sub]), "s"(fX)
+                         : "memory");
+        }
+    };
+    auto xconvert = [&]() {                      // xs -> fp16 hi / lo chunks in the slot recorded by xload
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const f32x4 lo4 = __builtin_bit_cast(f32x4, xs[sub][0]), hi4 = __builtin_bit_cast(f32x4, xs[sub][1]);
+            const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            h8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = v[e] * xscale[sub];
+                h[e] = (_Float16)t;
+                l[e] = (_Float16)(t - (float)h[e]);
+            }
+            const unsigned d = x_sa + xdst[sub];
+            asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:%3"
+                         :: "v"(d), "v"(__builtin_bit_cast(u32x4, h)), "v"(__builtin_bit_cast(u32x4, l)), "n"(CF::PLB)
+                         : "memory");
+        }
     };
     // piece pc = operand*4 + plane*2 + sub (operand 0 = R, plane 0 = hi)
     auto piece = [&](auto PC) {
-        constexpr int pc = decltype(PC)::value, op = pc >> 2, plane = (pc >> 1) & 1, sub = pc & 1;
+        constexpr int pc0 = decltype(PC)::value;
+        if constexpr (RF32 && pc0 >= 4) return;                   // only the four column-operand pieces exist; they go first
+        constexpr int pc = RF32 ? pc0 + 4 : pc0, op = pc >> 2, plane = (pc >> 1) & 1, sub = pc & 1;
         const unsigned dst = fill_sa + (unsigned)(op * CF::OPB_R + plane * CF::PLB + sub * (THREADS * 16)) + wbase;
         const unsigned long long base = op == 0 ? (plane == 0 ? fRhi : fRlo) : (plane == 0 ? fChi : fClo);
         glds_piece(op == 0 ? offR[sub] : offC[sub], base, __builtin_amdgcn_readfirstlane(dst));
@@ -705,11 +759,22 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
 
     // prologue: stage 0 landed and visible, stage 1 in flight, operands of the first B group (C_lo, R_hi of slice 0) in flight
     fill_begin(0, 0);
+    if constexpr (RF32) xload();
     fill_all();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (RF32) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[1][0]), "+v"(xs[1][1])::"memory");
+        xconvert();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (nkt > 1) { fill_begin(1, 1); fill_all(); }
+    if (nkt > 1) {
+        fill_begin(1, 1);
+        if constexpr (RF32) { xload(); conv_pending = true; }
+        fill_all();
+    }
     rd_fc(1, 0, 0, 1);
     rd_fr(1, 0, 0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
@@ -732,7 +797,10 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                     fill_on = kt + 2 < nkt;
-                    if (fill_on) fill_begin(kt + 2, kt & 1);
+                    if (fill_on) {
+                        fill_begin(kt + 2, kt & 1);
+                        if constexpr (RF32) { xload(); conv_pending = true; }
+                    }
                 }
             }
             // ---- C: R_hi . C_hi (fr[1], fc[0]); meanwhile fetch the next slice's C_lo -> fc[1]
@@ -754,6 +822,16 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
             }
             if (ks == 0) mm(I0{}, I0{}, I0{}, I0{}, false);
             else mm(I0{}, I0{}, I2{}, I2{}, fill_on);              // pieces 2,3
+            if constexpr (RF32) {
+                if (ks == 0 && conv_pending) {
+                    // the X loads are older than the four column-operand pieces issued since: vmcnt(4) = "X has landed"
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(4)" : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[1][0]), "+v"(xs[1][1])::"memory");
+                    xconvert();
+                    __builtin_amdgcn_sched_barrier(0);
+                    conv_pending = false;
+                }
+            }
         }
     }
 
@@ -771,6 +849,17 @@ __global__ __launch_bounds__(CfgX3::THREADS, CfgX3::WPS) void gemm_nt_x3_kernel(
     int r0, c0;
     tile_origin<CfgX3>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), r0, c0);
     gemm_tile_x3<MODE, EPI_SIM>(a, r0, c0, smem);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(CfgX3::THREADS, CfgX3::WPS) void gemm_nt_x3_fused_grouped_kernel(GroupedGemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lin = xcd_remap(blockIdx.x, g.tile_start[g.count]);
+    int p = 0;
+    while (p + 1 < g.count && lin >= g.tile_start[p + 1]) ++p;     // wave-uniform scalar search
+    int r0, c0;
+    tile_origin<CfgX3>(g.p[p], lin - g.tile_start[p], r0, c0);
+    gemm_tile_x3<MODE, EPI_FC, true>(g.p[p], r0, c0, smem);
 }
 
 template <int MODE>
@@ -922,6 +1011,25 @@ static hipError_t launch_grouped_x3(GroupedGemmArgs& g, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_nt_x3_grouped_kernel<GEMM_F16>), dim3((unsigned)grid), dim3(CfgX3::THREADS), CfgX3::SMEM, st, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_nt_x3_fused_grouped(GroupedGemmArgs& g, hipStream_t st) {
+    long nb = 0;
+    for (int i = 0; i < g.count; ++i) {
+        g.tile_start[i] = (int)nb;
+        nb += (long)((g.p[i].nR + CfgX3::TR - 1) / CfgX3::TR) * ((g.p[i].nC + CfgX3::TC - 1) / CfgX3::TC);
+    }
+    if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
+    g.tile_start[g.count] = (int)nb;
+    g.nbig = (int)nb;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = set_smem(gemm_nt_x3_fused_grouped_kernel<GEMM_F16>, CfgX3::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_x3_fused_grouped_kernel<GEMM_F16>), dim3((unsigned)nb), dim3(CfgX3::THREADS), CfgX3::SMEM, st, g);
     return hipGetLastError();
 }
 

@@ -11,6 +11,8 @@ enum { GEMM_F32 = 0, GEMM_F16 = 1, GEMM_BF16 = 2 };
 
 struct GemmArgs {
     const void* R;        // [nR, ldR] rows -> output rows
+    const float* Rf;      // x3 fused tile only: the row operand in fp32 [nR, ldRf]; split into hi/lo planes in the kernel
+    int ldRf;
     const void* C;        // [nC, ldC] rows -> output columns
     int nR, nC, K;        // K in elements (per segment)
     int ldR, ldC;         // elements
@@ -44,7 +46,8 @@ struct GroupedGemmArgs {
 
 hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool aligned, hipStream_t st);
 hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int staging, hipStream_t st);
-hipError_t launch_gemm_nt_grouped_f16(GroupedGemmArgs& g, hipStream_t st);   // fast staging only (packed operands)
+hipError_t launch_gemm_nt_grouped_f16(GroupedGemmArgs& g, hipStream_t st);
+hipError_t launch_gemm_nt_x3_fused_grouped(GroupedGemmArgs& g, hipStream_t st);   // fp32 row operand split in the kernel   // fast staging only (packed operands)
 int staging_kind(const GemmArgs& a, int esz, bool aligned);
 extern int g_gemm_variant;
 extern int g_num_cus;

@@ -32,11 +32,18 @@ float16 = False
 #: arithmetic of the FC projections: 'fp32' (v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 FMA chain) or 'fp16x3'
 #: (exact fp16 hi/lo operand split, 3 MFMA passes at the fp16 rate, ~2^-22 relative per product)
 FC_PRECISION = 'fp32'
+#: fp16x3 only: split the inputs inside the GEMM instead of materialising their hi/lo planes (LAFF_FUSED_SPLIT=0 disables)
+FUSED_SPLIT = os.environ.get('LAFF_FUSED_SPLIT', '1') != '0'
 
 
 def run_fc(pending):
     """Launch every queued FC projection as one grouped GEMM."""
     if FC_PRECISION == 'fp16x3':
+        # big launches take the fused split (inputs stay fp32 in HBM, split inside the GEMM); small ones the materialised split,
+        # whose 128x128 tiles fill the chip better
+        tiles = sum(((q['x'].shape[0] + 255) // 256) * ((q['weight_split'].N + 255) // 256) for q in pending)
+        if FUSED_SPLIT and tiles >= 512 and all(ops.fused_split_eligible(q['x'], q['weight_split']) for q in pending):
+            return ops.fc_act_bn_fused_grouped(pending)
         return ops.fc_act_bn_split_grouped(pending)
     if FC_PRECISION != 'fp32':
         raise ValueError("FC_PRECISION must be 'fp32' or 'fp16x3'")

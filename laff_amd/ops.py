@@ -10,9 +10,9 @@ import torch
 
 from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
-                   FcProblem, FcSplitProblem, Plane, check)
+                   FcProblem, FcSplitProblem, Plane, check, FcFusedProblem)
 
-__all__ = ['topk_rows', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['topk_rows', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -253,6 +253,59 @@ def fc_act_bn_split_grouped(problems):
         keep.append((xs, ws, vecs))
     lib, h = _context(dev)
     _call('fc_act_bn', lib.laff_fc_act_bn_split_grouped, h, arr, len(problems))
+    return outs
+
+
+def fused_split_eligible(x, weight_split):
+    """Can laff_fc_act_bn_fused_grouped take this input?  (fp32 CUDA matrix, 16-byte aligned rows, K a multiple of 32.)"""
+    return (torch.is_tensor(x) and x.is_cuda and x.layout == torch.strided and x.dtype == torch.float32 and x.dim() == 2 and
+            x.shape[1] % 32 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and
+            x.shape[1] == weight_split.K)
+
+
+def fc_act_bn_fused_grouped(problems):
+    """fc_act_bn_split_grouped without materialising the split of the inputs: one pass over the inputs for their per-row scales
+    (laff_row_scales_grouped), then the GEMM splits them on the way into LDS.  problems: dicts with x (fp32 tensor),
+    weight_split (SplitOperand of W), optional bias / bn_scale / bn_shift / activation / out."""
+    if not problems:
+        return []
+    n = len(problems)
+    dev = problems[0]['weight_split'].buf.device
+    lib, h = _context(dev)
+    X, N, K, LD, R = (C.c_void_p * n)(), (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)(), (C.c_void_p * n)()
+    arr = (FcFusedProblem * n)()
+    outs, keep = [], []
+    total = sum(q['x'].shape[0] for q in problems)
+    scales = torch.empty((max(total, 1),), device=dev, dtype=torch.float32)      # one buffer, one slice per problem
+    at = 0
+    for i, q in enumerate(problems):
+        x, ldx = _rows(q['x'], 'x')
+        ws = q['weight_split']
+        if not fused_split_eligible(x, ws):
+            raise ValueError('problem %d is not eligible for the fused split (see fused_split_eligible)' % i)
+        rs = scales[at:at + x.shape[0]]
+        at += x.shape[0]
+        X[i], N[i], K[i], LD[i], R[i] = x.data_ptr(), x.shape[0], x.shape[1], ldx, rs.data_ptr()
+        D = ws.N
+        vecs = []
+        for nm in ('bias', 'bn_scale', 'bn_shift'):
+            t = q.get(nm)
+            if t is not None:
+                _dev(t, nm)
+                if t.numel() != D or not t.is_contiguous():
+                    raise ValueError('%s must be a contiguous vector of %d' % (nm, D))
+            vecs.append(t)
+        out = q.get('out')
+        if out is None:
+            out = torch.empty((x.shape[0], D), device=dev, dtype=torch.float32)
+        y, ldy = _rows(out, 'out')
+        arr[i] = FcFusedProblem(x.data_ptr(), ldx, rs.data_ptr(), x.shape[0], x.shape[1], ws.buf.data_ptr(), ws.rscale.data_ptr(),
+                                *[t.data_ptr() if t is not None else None for t in vecs], D, ACT[q.get('activation')],
+                                y.data_ptr(), ldy)
+        outs.append(out)
+        keep.append((x, ws, vecs))
+    _call('row_scales', lib.laff_row_scales_grouped, h, n, X, N, K, LD, R)
+    _call('fc_act_bn', lib.laff_fc_act_bn_fused_grouped, h, arr, n)
     return outs
 
 

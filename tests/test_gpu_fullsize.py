@@ -275,3 +275,34 @@ def test_split_fc_with_tail_split_matches_fp32_path():
     for i in (0, 3, 4, 5, 7):
         ref = ops.fc_act_bn(X[i], W[i], b, sc, sh, 'tanh')
         assert float((outs[i] - ref).abs().max()) <= 2e-5
+
+
+def test_fused_input_split_is_bit_identical_to_the_materialised_split():
+    """laff_fc_act_bn_fused_grouped (inputs split inside the GEMM) against laff_split_rows + laff_fc_act_bn_split_grouped on the
+    same big tiles: the planes are formed by the same arithmetic, so the outputs agree bit for bit wherever both paths use
+    256x256 tiles -- compared here on problems without a sparse last round (no tail split on the materialised side)."""
+    from laff_amd import ops
+    torch.manual_seed(1)
+    rows = [32768] * 8                                # 8 x 128 x 2 = 2,048 big tiles = 8 full rounds of 256 CUs
+    W = [torch.randn(512, 512, device=DEV) / 22 for _ in rows]
+    Ws = [ops.split_rows(w) for w in W]
+    X = [torch.randn(n, 512, device=DEV) for n in rows]
+    X[2][5] *= 3e4
+    X[6][9] *= 1e-6
+    X[3][100] = 0                                     # an all-zero row (scale 1)
+    b = torch.randn(512, device=DEV) * 0.1
+    sc = torch.rand(512, device=DEV) + 0.5
+    sh = torch.randn(512, device=DEV) * 0.1
+    probs = [dict(x=X[i], weight_split=Ws[i], bias=b, bn_scale=sc, bn_shift=sh, activation='tanh') for i in range(8)]
+    fused = ops.fc_act_bn_fused_grouped(probs)
+    split = ops.fc_act_bn_split_grouped(probs)
+    for f, s_ in zip(fused, split):
+        assert torch.equal(f, s_)
+    ref = ops.fc_act_bn(X[2], W[2], b, sc, sh, 'tanh')
+    assert float((fused[2] - ref).abs().max()) <= 2e-5
+    # a strided view of a wider matrix and a ragged row count
+    big = torch.randn(1000, 1024, device=DEV)
+    view = big[:, 256:768]
+    out = ops.fc_act_bn_fused_grouped([dict(x=view, weight_split=Ws[0], bias=b, activation=None)])[0]
+    ref = ops.fc_act_bn(view.contiguous(), W[0], b, None, None, None)
+    assert float((out - ref).abs().max()) <= 2e-5

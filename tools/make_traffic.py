@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-ENTRY = [('gemm_nt_x3_grouped_kernel', 'fc_act_bn'), ('gemm_nt_grouped_kernel', 'fc_act_bn'), ('gemm_nt_x3_kernel', 'sim_gemm'),
+ENTRY = [('gemm_nt_x3_fused_grouped_kernel', 'fc_act_bn'), ('gemm_nt_x3_grouped_kernel', 'fc_act_bn'), ('gemm_nt_grouped_kernel', 'fc_act_bn'), ('gemm_nt_x3_kernel', 'sim_gemm'),
          ('gemm_nt_kernel', 'sim_gemm'), ('split_rows_kernel', 'split_rows'), ('fuse_reg_kernel', 'fuse'), ('fuse_stream_kernel', 'fuse'),
          ('frame_fuse_kernel', 'frame_fuse'), ('row_dot_gt_kernel', 'row_dot_gt'), ('fc_gather_kernel', 'fc_gather'),
          ('rank_metrics_kernel', 'rank_metrics'), ('pack_rows_kernel', 'pack_rows')]
