@@ -483,6 +483,16 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
 // magnitude, lo stays normal down to 2^-34 of the row maximum), hi = fp16(x*s), lo = fp16(x*s - hi).  fp16 x fp16
 // products are exact in fp32, so hi*hi' + hi*lo' + lo*hi' reproduces the fp32 product to ~2^-22 relative.
 // out: [2][N][Kp] fp16 (hi plane, lo plane), columns >= K zero filled; rscale[n] = 1/s (a power of two: exact).
+// binary exponent of a row maximum for the hi/lo split (row max * 2^(9-e) lands in [512, 1024)), straight from the bits: 0 for
+// an all-zero / non-finite row, clamped to [-100, 127] so that both 2^(9-e) and 2^(e-9) stay normal floats (a row whose
+// largest magnitude is below 2^-100 is all denormal after scaling either way)
+__device__ __forceinline__ int split_exponent(float m) {
+    const int be = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    if (!(m > 0.f) || be == 0xff) return 0;
+    return max(be - 127, -100);
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+
 struct SplitArgs {              // up to 8 matrices in one launch; block -> (matrix, group of 4 rows) by scalar search
     int count;
     int block_start[9];
@@ -516,10 +526,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs g) {
             m = fmaxf(fmaxf(m, fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
         }
         m = wave_max(m);
-        int e = 0;
-        if (m > 0.f && m < INFINITY) e = ilogbf(m);
-        const float s = ldexpf(1.0f, 9 - e);
-        if (lane == 0) g.rscale[p][n] = ldexpf(1.0f, e - 9);
+        const int e = split_exponent(m);
+        const float s = pow2f(9 - e);
+        if (lane == 0) g.rscale[p][n] = pow2f(e - 9);
         if (!g.out[p]) return;                                   // scales only (laff_row_scales_grouped)
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -539,10 +548,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(SplitArgs g) {
     } else {
         for (int c = lane; c < K; c += 64) m = fmaxf(m, fabsf(src[c]));
         m = wave_max(m);
-        int e = 0;
-        if (m > 0.f && m < INFINITY) e = ilogbf(m);
-        const float s = ldexpf(1.0f, 9 - e);
-        if (lane == 0) g.rscale[p][n] = ldexpf(1.0f, e - 9);
+        const int e = split_exponent(m);
+        const float s = pow2f(9 - e);
+        if (lane == 0) g.rscale[p][n] = pow2f(e - 9);
         if (!g.out[p]) return;
         for (int c = lane * 4; c < Kp; c += 256) {       // Kp % 64 == 0, rows of the packed operand are 128-byte aligned
             h4 h, l;
