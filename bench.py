@@ -314,6 +314,7 @@ def main():
             'row_scales': ('hbm', 4.0 * (nvl * sum(fc_v) + ntl * sum(fc_t)), HBM_PEAK_GBS, 1e9, 'GB/s'),
             'fuse': ('hbm', 4.0 * K * (nvl * (Lv + 1 - (1 if raw_v else 0)) + ntl * (Lt + 1 - (1 if raw_t else 0)))
                      + 4.0 * (nvl * raw_v + ntl * raw_t), HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'frame_fuse': ('hbm', 4.0 * d * 4 * ((float(lens[v0:v1].sum()) if lens is not None else 0.0) + nvl), HBM_PEAK_GBS, 1e9, 'GB/s'),
             'fc_gather': ('hbm', 4.0 * K * (sum(gather_dims) + ntl) + 8.0 * sparse_nnz, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'pack_rows': ('hbm', (4.0 + 2.0 * (2 if x3 == 3 else 1)) * (ntl + nvl) * K, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'rank_count': ('hbm', 4.0 * Nt * nvl, HBM_PEAK_GBS, 1e9, 'GB/s'),

@@ -39,10 +39,12 @@ FUSED_SPLIT = os.environ.get('LAFF_FUSED_SPLIT', '1') != '0'
 def run_fc(pending):
     """Launch every queued FC projection as one grouped GEMM."""
     if FC_PRECISION == 'fp16x3':
-        # big launches take the fused split (inputs stay fp32 in HBM, split inside the GEMM); small ones the materialised split,
-        # whose 128x128 tiles fill the chip better
+        # big launches with a narrow output take the fused split (inputs stay fp32 in HBM, split inside the GEMM: every column
+        # tile of a row block repeats the conversion, 2x at D = 512 but 16x at D = 4096, where materialising the planes once is
+        # cheaper: C5 33.2 ms fused vs 32.9 ms); small launches take the materialised split, whose 128x128 tiles fill the chip
         tiles = sum(((q['x'].shape[0] + 255) // 256) * ((q['weight_split'].N + 255) // 256) for q in pending)
-        if FUSED_SPLIT and tiles >= 512 and all(ops.fused_split_eligible(q['x'], q['weight_split']) for q in pending):
+        if (FUSED_SPLIT and tiles >= 512 and all(q['weight_split'].N <= 1024 for q in pending) and
+                all(ops.fused_split_eligible(q['x'], q['weight_split']) for q in pending)):
             return ops.fc_act_bn_fused_grouped(pending)
         return ops.fc_act_bn_split_grouped(pending)
     if FC_PRECISION != 'fp32':
