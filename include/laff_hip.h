@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 6
+#define LAFF_ABI_VERSION 7
 
 enum {
     LAFF_OK = 0,
@@ -180,6 +180,11 @@ int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int 
 int laff_frame_fuse(laff_ctx* ctx, const float* frames, const int* lens, int B, int Fmax, int d,
                     const float* w /*[d]*/, const float* b /*[1]*/, const float* gw /*[1]*/, unsigned flags,
                     float* V);
+/* the frame features of one tower (same B / Fmax / d / flags / lens, own frames, attention parameters and output) in ONE
+ * launch: host arrays of `count` device pointers (gw may be NULL without WITH_AVE) */
+int laff_frame_fuse_grouped(laff_ctx* ctx, int count, const float* const* frames, const int* lens, int B, int Fmax, int d,
+                            const float* const* w, const float* const* b, const float* const* gw, unsigned flags,
+                            float* const* V);
 
 /* ---- a8: loss.l2norm (loss.py:8-13) + operand packing for the similarity GEMM ---------------------------
  * For each (n,h): y = x / (||x||_2 + eps + 1e-14) if normalize, then y * prescale, converted to `precision`.

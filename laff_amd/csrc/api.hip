@@ -430,21 +430,34 @@ int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int 
     return LAFF_OK;
 }
 
-int laff_frame_fuse(laff_ctx* ctx, const float* frames, const int* lens, int B, int Fmax, int d, const float* w,
-                    const float* b, const float* gw, unsigned flags, float* V) {
+int laff_frame_fuse_grouped(laff_ctx* ctx, int count, const float* const* frames, const int* lens, int B, int Fmax, int d,
+                            const float* const* w, const float* const* b, const float* const* gw, unsigned flags, float* const* V) {
     CHECK_CTX(ctx);
-    if (B == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
-    if (!frames || !w || !b || !V) return fail(LAFF_E_ARG, "laff_frame_fuse: null frames/w/b/V");
+    if (B == 0 || count == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
+    if (count < 0 || !frames || !w || !b || !V) return fail(LAFF_E_ARG, "laff_frame_fuse: null frames/w/b/V");
     if (B < 0 || Fmax < 1 || d < 4 || (d & 3) || d > 1024)
         return fail(LAFF_E_SHAPE, "laff_frame_fuse: need B>=0, Fmax>=1, d%%4==0, d<=1024 (B=%d Fmax=%d d=%d)", B, Fmax, d);
-    if ((flags & LAFF_ATT_WITH_AVE) && !gw) return fail(LAFF_E_ARG, "laff_frame_fuse: WITH_AVE needs gw");
     if (flags & ~(unsigned)(LAFF_ATT_WITH_AVE | LAFF_ATT_MUL)) return fail(LAFF_E_UNSUPPORTED, "laff_frame_fuse: flags 0x%x", flags);
-    if (!aligned16(frames) || !aligned16(w) || !aligned16(V)) return fail(LAFF_E_ALIGN, "laff_frame_fuse: 16-byte alignment");
-    if (B == 0) return LAFF_OK;
-    laff::FrameArgs a{frames, lens, B, Fmax, d, w, b, gw, flags, V};
+    if ((long)B * (count < 8 ? count : 8) > 0x7fffffffL) return fail(LAFF_E_SHAPE, "laff_frame_fuse: grid too large");
     DeviceGuard g(ctx->device);
-    HIP_TRY(laff::launch_frame_fuse(a, ctx->stream));
+    for (int i0 = 0; i0 < count; i0 += 8) {
+        laff::FrameGroup grp{};
+        grp.count = count - i0 < 8 ? count - i0 : 8;
+        for (int i = 0; i < grp.count; ++i) {
+            const int k = i0 + i;
+            if (!frames[k] || !w[k] || !b[k] || !V[k]) return fail(LAFF_E_ARG, "laff_frame_fuse: feature %d has a null pointer", k);
+            if ((flags & LAFF_ATT_WITH_AVE) && (!gw || !gw[k])) return fail(LAFF_E_ARG, "laff_frame_fuse: WITH_AVE needs gw");
+            if (!aligned16(frames[k]) || !aligned16(w[k]) || !aligned16(V[k])) return fail(LAFF_E_ALIGN, "laff_frame_fuse: 16-byte alignment");
+            grp.f[i] = laff::FrameArgs{frames[k], lens, B, Fmax, d, w[k], b[k], gw ? gw[k] : nullptr, flags, V[k]};
+        }
+        HIP_TRY(laff::launch_frame_fuse(grp, ctx->stream));
+    }
     return LAFF_OK;
+}
+
+int laff_frame_fuse(laff_ctx* ctx, const float* frames, const int* lens, int B, int Fmax, int d, const float* w,
+                    const float* b, const float* gw, unsigned flags, float* V) {
+    return laff_frame_fuse_grouped(ctx, 1, &frames, lens, B, Fmax, d, &w, &b, gw ? &gw : nullptr, flags, &V);
 }
 
 int laff_packed_bytes(int N, int K, int precision, size_t* out) {

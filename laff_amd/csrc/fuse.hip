@@ -286,12 +286,15 @@ hipError_t launch_fuse(const FuseArgs& a, hipStream_t st) {
 // Wave w walks frames w, w+4, ...; online softmax per wave, merged through LDS.  Columns: lane i owns
 // {256*j + 4*i .. +3}, j < NCH (d <= 1024).
 template <int NCH>
-__global__ __launch_bounds__(256) void frame_fuse_kernel(FrameArgs a) {
+__global__ __launch_bounds__(256) void frame_fuse_kernel(FrameGroup grp) {
     __shared__ __attribute__((aligned(16))) float sh_acc[4][NCH * 256];
     __shared__ __attribute__((aligned(16))) float sh_sum[4][NCH * 256];
     __shared__ float sh_m[4], sh_s[4], sh_red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bidx = blockIdx.x;
+    // all frame features of the tower share one launch: 3,000 videos alone are 1.5 rounds of workgroup slots, 4 x 3,000 fill them
+    const int feat = (int)blockIdx.x / grp.f[0].B;
+    const FrameArgs& a = grp.f[feat];
+    const int bidx = (int)blockIdx.x - feat * a.B;
     const int d = a.d, Fmax = a.Fmax;
     const int len = a.lens ? min(max(a.lens[bidx], 0), Fmax) : Fmax;
     const float* base = a.frames + (long)bidx * Fmax * d;
@@ -407,13 +410,15 @@ __global__ __launch_bounds__(256) void frame_fuse_kernel(FrameArgs a) {
     }
 }
 
-hipError_t launch_frame_fuse(const FrameArgs& a, hipStream_t st) {
+hipError_t launch_frame_fuse(const FrameGroup& g, hipStream_t st) {
+    const FrameArgs& a = g.f[0];
+    const dim3 grid((unsigned)((long)a.B * g.count));
     if (a.d <= 256)
-        hipLaunchKernelGGL((frame_fuse_kernel<1>), dim3(a.B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((frame_fuse_kernel<1>), grid, dim3(256), 0, st, g);
     else if (a.d <= 512)
-        hipLaunchKernelGGL((frame_fuse_kernel<2>), dim3(a.B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((frame_fuse_kernel<2>), grid, dim3(256), 0, st, g);
     else if (a.d <= 1024)
-        hipLaunchKernelGGL((frame_fuse_kernel<4>), dim3(a.B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((frame_fuse_kernel<4>), grid, dim3(256), 0, st, g);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

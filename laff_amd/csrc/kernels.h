@@ -84,7 +84,11 @@ struct FrameArgs {
     unsigned flags;
     float* V;             // [B, d]
 };
-hipError_t launch_frame_fuse(const FrameArgs& a, hipStream_t st);
+struct FrameGroup {       // up to 8 frame features of the same shape in ONE launch: block -> (feature, video)
+    int count;
+    FrameArgs f[8];
+};
+hipError_t launch_frame_fuse(const FrameGroup& g, hipStream_t st);
 
 hipError_t launch_split_rows_grouped(int count, const float* const* X, const int* N, const int* K, const int* ldx, void* const* out,
                                      float* const* rscale, hipStream_t st);

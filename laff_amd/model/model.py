@@ -463,12 +463,26 @@ class VisMutiTransformNetPlusFrameFeat(nn.Module):
         _eval_only(self)
         if self.opt.frame_feat_with_video_feat is False:
             vis_input = {}
-        for feat_name in vis_frame_feat_dict_input:
-            if feat_name == 'mask_tensor':
-                continue
+        names = [k for k in vis_frame_feat_dict_input if k != 'mask_tensor']
+        for feat_name in names:
             vis_frame_feat_dict_input[feat_name] = to_device_and_float16(vis_frame_feat_dict_input[feat_name])
-            vis_input[feat_name] = self.frame_vector(feat_name, vis_frame_feat_dict_input[feat_name],
-                                                     vis_frame_feat_dict_input['mask_tensor'])
+        shapes = {tuple(vis_frame_feat_dict_input[k].shape) for k in names}
+        if len(names) > 1 and len(shapes) == 1 and not self.opt.vis_frame_addFC:
+            # every frame feature of the tower in ONE launch (same shape, same attention type, shared lens)
+            frames = [vis_frame_feat_dict_input[k].contiguous() for k in names]
+            lens = vis_frame_feat_dict_input['mask_tensor'].to(device=frames[0].device).sum(dim=1).to(torch.int32).contiguous()
+            atts = [self.frame_attention[k][-1] for k in names]
+            params = []
+            for att in atts:
+                w, b, gw = att._params()
+                params.append((w.reshape(-1), b, gw))
+            vecs = ops.frame_fuse_grouped(frames, lens, params, ops.attention_flags(atts[0].with_ave, atts[0].mul))
+            for k, v in zip(names, vecs):
+                vis_input[k] = v
+        else:
+            for feat_name in names:
+                vis_input[feat_name] = self.frame_vector(feat_name, vis_frame_feat_dict_input[feat_name],
+                                                         vis_frame_feat_dict_input['mask_tensor'])
         heads = self.opt.multi_head_attention['heads']
         module_dict = dict(self.named_children())
         planes = []

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, FcSplitProblem, Plane, check, FcFusedProblem)
 
-__all__ = ['topk_rows', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['topk_rows', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -370,6 +370,27 @@ def frame_fuse(frames, lens, w, b, gw, flags):
     _call('frame_fuse', lib.laff_frame_fuse, h, _ptr(frames), _ptr(lens), B, Fmax, d, _ptr(_dev(w, 'w')), _ptr(_dev(b, 'b')),
                               _ptr(gw), flags, _ptr(V))
     return V
+
+
+def frame_fuse_grouped(frames_list, lens, params, flags):
+    """frame_fuse for several frame features of the same shape in one launch.  frames_list: [(B, Fmax, d)], params: [(w, b, gw)]."""
+    n = len(frames_list)
+    B, Fmax, d = frames_list[0].shape
+    F, W, Bb, G, Vv = ((C.c_void_p * n)() for _ in range(5))
+    outs, keep = [], []
+    for i, (fr, (w, b, gw)) in enumerate(zip(frames_list, params)):
+        _dev(fr, 'frames')
+        if tuple(fr.shape) != (B, Fmax, d) or not fr.is_contiguous():
+            raise ValueError('grouped frame features must share one contiguous (B, Fmax, d) shape')
+        V = torch.empty((B, d), device=fr.device, dtype=torch.float32)
+        F[i], W[i], Bb[i], G[i], Vv[i] = fr.data_ptr(), _dev(w, 'w').data_ptr(), _dev(b, 'b').data_ptr(), _ptr(gw), V.data_ptr()
+        outs.append(V)
+        keep.append((fr, w, b, gw))
+    if lens is not None:
+        _dev(lens, 'lens', torch.int32)
+    lib, h = _context(frames_list[0].device)
+    _call('frame_fuse', lib.laff_frame_fuse_grouped, h, n, F, _ptr(lens), B, Fmax, d, W, Bb, G, flags, Vv)
+    return outs
 
 
 def default_prescale(precision):

@@ -600,3 +600,24 @@ def test_fuse_plane_activation_equals_activation_in_the_projection(act):
     E1 = ops.fuse(fused_in_fc, H, d, w, b, gw, flags)
     E2 = ops.fuse(deferred, H, d, w, b, gw, flags)
     assert torch.equal(E1, E2)
+
+
+def test_frame_fuse_grouped_equals_per_feature_launches():
+    from laff_amd import ops
+    g = rnd(12)
+    B, Fmax, d = 37, 9, 128
+    lens = g.integers(0, Fmax + 1, B).astype(np.int32)
+    frames, params = [], []
+    for _ in range(5):
+        f = np.zeros((B, Fmax, d), np.float32)
+        for i in range(B):
+            f[i, :lens[i]] = g.normal(0, 1, (lens[i], d))
+        frames.append(dev(f))
+        params.append((dev(g.normal(0, 0.2, d).astype(np.float32)), dev(g.normal(0, 0.2, 1).astype(np.float32)),
+                       dev(g.uniform(0, 1, 1).astype(np.float32))))
+    ld = dev(lens, torch.int32)
+    for with_ave, mul in O.FRAME_ATTENTION_FLAGS.values():
+        flags = ops.attention_flags(with_ave, mul)
+        grouped = ops.frame_fuse_grouped(frames, ld, params, flags)
+        for f, (w, b, gw), v in zip(frames, params, grouped):
+            assert torch.equal(v, ops.frame_fuse(f, ld, w, b, gw, flags))
