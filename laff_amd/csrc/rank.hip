@@ -323,7 +323,8 @@ hipError_t launch_v2t_count(const float* S, int Nt, int Nv, int lds, const int* 
 namespace laff {
 
 __device__ __forceinline__ unsigned f2key(float f) {
-    const unsigned b = __float_as_uint(f);
+    unsigned b = __float_as_uint(f);
+    if (b == 0x80000000u) b = 0u;                    // -0.0 == +0.0 for argsort: one key, ties resolved by index
     return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
 }
 __device__ __forceinline__ float key2f(unsigned k) {

@@ -174,3 +174,63 @@ def test_fused_ranking_random_shapes_is_self_consistent(seed, Nt, Nv, H, dq, pre
     # 16-bit operand rounding is relative to the element size ~ 1/sqrt(d): the 1e-4 contract is quoted at d = 512
     h = 1e-3 / np.sqrt(d) + 1e-4
     assert np.abs(S - ref).max() <= {'fp16': h, 'fp16x3': 2e-6, 'bf16': 8 * h}[precision]
+
+
+@gpu
+@settings(max_examples=20, **COMMON)
+@given(seed=st.integers(0, 10 ** 6), B=st.integers(1, 60), Fmax=st.integers(1, 40), dq=st.integers(1, 64), with_ave=st.booleans(),
+       mul=st.booleans(), use_lens=st.booleans())
+def test_frame_attention_random_shapes_vs_oracle(seed, B, Fmax, dq, with_ave, mul, use_lens):
+    import torch
+    from laff_amd import ops
+    d = 4 * dq
+    g = np.random.default_rng(seed)
+    lens = g.integers(0, Fmax + 1, B).astype(np.int32)
+    frames = np.zeros((B, Fmax, d), np.float32)
+    for i in range(B):
+        frames[i, :lens[i]] = g.normal(0, 1, (lens[i], d))
+    w = (g.uniform(-1, 1, d) / np.sqrt(d)).astype(np.float32)
+    b, gw = np.float32(g.normal(0, 0.3)), np.float32(g.uniform(0, 1))
+    got = ops.frame_fuse(_dev(frames), _dev(lens, torch.int32) if use_lens else None, _dev(w), _dev(b).view(1), _dev(gw).view(1),
+                         ops.attention_flags(with_ave, mul)).cpu().numpy()
+    ref = O.frame_attention(frames, w, b, with_ave, mul, gw)
+    m = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), m)
+    if m.any():
+        assert np.abs(got[m] - ref[m]).max() <= 3e-6
+
+
+@gpu
+@settings(max_examples=20, **COMMON)
+@given(seed=st.integers(0, 10 ** 6), Nt=st.integers(1, 40), Nv=st.integers(1, 3000), K=st.integers(1, 600))
+def test_topk_random_shapes_vs_stable_argsort(seed, Nt, Nv, K):
+    from laff_amd import ops
+    g = np.random.default_rng(seed)
+    S = g.normal(0, 1, (Nt, Nv)).astype(np.float32)
+    S[:, : Nv // 3] = np.round(S[:, : Nv // 3], 1)            # plenty of exact ties
+    k = min(K, Nv)
+    idx, val = ops.topk_rows(_dev(S), k)
+    ref = np.argsort(S, axis=1, kind='stable')[:, ::-1][:, :k]
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(val.cpu().numpy(), np.take_along_axis(S, ref, axis=1))
+
+
+@gpu
+@settings(max_examples=15, **COMMON)
+@given(seed=st.integers(0, 10 ** 6), B=st.integers(1, 200), H=st.sampled_from([1, 2, 8]), dq=st.integers(1, 40), maxv=st.booleans(),
+       mean=st.booleans(), direction=st.sampled_from(['i2t', 't2i', 'bidir']))
+def test_margin_loss_random_shapes_vs_oracle(seed, B, H, dq, maxv, mean, direction):
+    from laff_amd import ops
+    d = 4 * dq
+    g = np.random.default_rng(seed)
+    z = g.normal(0, 1, (B, 8)).astype(np.float32)
+    P = g.normal(0, 1, (8, H * d)).astype(np.float32)
+    s = (z @ P + 2.0 * g.normal(0, 1, (B, H * d))).astype(np.float32).reshape(B, H, d)
+    im = (z @ P + 2.0 * g.normal(0, 1, (B, H * d))).astype(np.float32).reshape(B, H, d)
+    style = 'mean' if mean else 'sum'
+    loss, d_s, d_im = ops.margin_loss(_dev(s), _dev(im), 0.2, maxv, style, direction)
+    rl, rs, ri = O.margin_ranking_loss(s, im, 0.2, maxv, style, direction)
+    assert abs(loss.item() - float(rl)) <= 1e-4 * max(1.0, abs(float(rl)))
+    # a decision flipped by a 1-ulp score difference moves whole gradient rows: robust comparison
+    bad = max((np.abs(d_s.cpu().numpy() - rs).max(axis=-1) > 1e-5).mean(), (np.abs(d_im.cpu().numpy() - ri).max(axis=-1) > 1e-5).mean())
+    assert bad <= 0.03
