@@ -234,3 +234,23 @@ def test_margin_loss_random_shapes_vs_oracle(seed, B, H, dq, maxv, mean, directi
     # a decision flipped by a 1-ulp score difference moves whole gradient rows: robust comparison
     bad = max((np.abs(d_s.cpu().numpy() - rs).max(axis=-1) > 1e-5).mean(), (np.abs(d_im.cpu().numpy() - ri).max(axis=-1) > 1e-5).mean())
     assert bad <= 0.03
+
+
+@gpu
+@settings(max_examples=20, **COMMON)
+@given(seed=st.integers(0, 10 ** 6), nv=st.integers(1, 60), max_caps=st.integers(1, 25))
+def test_both_retrieval_directions_random_groupings_vs_oracle(seed, nv, max_caps):
+    """predictor.py:232-270 on the device for an arbitrary number of captions per video (1 .. max_caps, some videos with many):
+    T2V and V2T metrics equal the argsort / label-matrix restatement when scores are distinct."""
+    from laff_amd import predictor as P
+    g = np.random.default_rng(seed)
+    caps = g.integers(1, max_caps + 1, nv)
+    txt_ids, vis_ids = [], ['vid%d' % v for v in range(nv)]
+    for v in g.permutation(nv):
+        txt_ids += ['vid%d#%d' % (v, c) for c in range(caps[v])]
+    nt = len(txt_ids)
+    S = (g.permutation(nt * nv).reshape(nt, nv) / float(nt * nv)).astype(np.float32)         # all distinct
+    t2v, v2t = P.retrieval_metrics(S, txt_ids, vis_ids)
+    rt, rv = O.predictor_metrics(S, txt_ids, vis_ids)
+    np.testing.assert_allclose(t2v, rt, rtol=1e-12)
+    np.testing.assert_allclose(v2t, rv, rtol=1e-12)
