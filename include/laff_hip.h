@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 7
+#define LAFF_ABI_VERSION 8
 
 enum {
     LAFF_OK = 0,
@@ -207,9 +207,10 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
 /* Ground-truth pre-pass for the fused count: s_gt[t] = scale * <T[t], V[gt_col[t]-col0]> on the packed operands
  * (fp32 accumulation of the same 16-bit products), -inf when that column is outside [0,Nv).  When laff_sim_gemm is
  * then called with gt_col/s_gt it writes exactly this value at S[t, gt] so counts and S stay consistent.
- * 16-bit precisions only. */
+ * 16-bit precisions only.  zero_count (nullable, [Nt]) is cleared on the way: it is the accumulator the fused count of
+ * laff_sim_gemm adds into (saves a fill launch). */
 int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
-                    const int* gt_col, int col0, float* s_gt);
+                    const int* gt_col, int col0, float* s_gt, int* zero_count);
 
 /* s_gt[t] = S[t, gt_col[t]-col0] if that column is in [0,Nv) else -inf  (shard-local ground-truth score) */
 int laff_gather_gt(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0,
@@ -229,12 +230,14 @@ int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const
 int laff_topk_rows(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, int K, int* idx_out, float* val_out);
 
 /* ---- a13: evaluation.eval (evaluation.py:92-109) for single-GT rows ---------------------------------------
- * rank1[Nq] device int32, 1-based.  out7 (host) = r1, r5, r10, medr, meanr, mir, mAP.  Reduced on the device
- * (one small kernel), 56 bytes copied back; synchronises the stream. */
-int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, double out7[7]);
+ * rank[i] = r[i] + base must be >= 1: pass 1-based ranks with base = 0, or the counts of better-scoring videos that
+ * laff_sim_gemm / laff_rank_count produce with base = 1; ranks_out (nullable, [Nq] device) receives the ranks.
+ * out7 (host) = r1, r5, r10, medr, meanr, mir, mAP.  Reduced on the device (one small kernel), 56 bytes copied back;
+ * synchronises the stream. */
+int laff_rank_metrics(laff_ctx* ctx, const int* r, int Nq, int base, int* ranks_out, double out7[7]);
 /* Same, without synchronising: out8 is PINNED HOST memory (8 doubles: the 7 metrics + an error flag word, non-zero if a
  * rank < 1 was seen); valid once the stream has been synchronised.  Capturable in a HIP graph. */
-int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, double* out8_pinned_host);
+int laff_rank_metrics_async(laff_ctx* ctx, const int* r, int Nq, int base, int* ranks_out, double* out8_pinned_host);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get('LAFF_HIP_LIB') or os.path.join(_HERE, 'lib', 'liblaff
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class Plane(C.Structure):
@@ -63,13 +63,13 @@ SIGNATURES = {
     'laff_packed_bytes': (C.c_int, [_I, _I, _I, C.POINTER(C.c_size_t)]),
     'laff_pack_rows': (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
     'laff_sim_gemm': (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P]),
-    'laff_row_dot_gt': (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P]),
+    'laff_row_dot_gt': (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P, _P]),
     'laff_gather_gt': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P]),
     'laff_rank_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I]),
     'laff_topk_rows': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
     'laff_v2t_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _I, _P]),
-    'laff_rank_metrics': (C.c_int, [_P, _P, _I, C.POINTER(C.c_double)]),
-    'laff_rank_metrics_async': (C.c_int, [_P, _P, _I, _P]),
+    'laff_rank_metrics': (C.c_int, [_P, _P, _I, _I, _P, C.POINTER(C.c_double)]),
+    'laff_rank_metrics_async': (C.c_int, [_P, _P, _I, _I, _P, _P]),
 }
 
 _lib = None

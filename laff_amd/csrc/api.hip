@@ -571,7 +571,7 @@ int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const
 }
 
 int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
-                    const int* gt_col, int col0, float* s_gt) {
+                    const int* gt_col, int col0, float* s_gt, int* zero_count) {
     CHECK_CTX(ctx);
     if (Nt == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!T || !V || !gt_col || !s_gt) return fail(LAFF_E_ARG, "laff_row_dot_gt: null argument");
@@ -581,11 +581,11 @@ int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv,
     if (Nt == 0) return LAFF_OK;
     const int bf16 = (precision == LAFF_PREC_BF16 || precision == LAFF_PREC_BF16X3);
     DeviceGuard g(ctx->device);
-    HIP_TRY(laff::launch_row_dot_gt(T, V, Nt, Nv, K, bf16, is_x3(precision) ? 1 : 0, scale, gt_col, col0, s_gt, ctx->stream));
+    HIP_TRY(laff::launch_row_dot_gt(T, V, Nt, Nv, K, bf16, is_x3(precision) ? 1 : 0, scale, gt_col, col0, s_gt, zero_count, ctx->stream));
     return LAFF_OK;
 }
 
-int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, double* out8) {
+int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, int base, int* ranks_out, double* out8) {
     CHECK_CTX(ctx);
     if (!rank1 || !out8) return fail(LAFF_E_ARG, "laff_rank_metrics_async: null argument");
     if (Nq < 1) return fail(LAFF_E_SHAPE, "laff_rank_metrics_async: Nq=%d", Nq);
@@ -594,12 +594,12 @@ int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, double* out
         HIP_TRY(hipMalloc((void**)&ctx->d_metrics, 8 * sizeof(double)));
         HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
     }
-    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, ctx->d_metrics, (int*)(ctx->d_metrics + 7), ctx->stream));
+    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, (int*)(ctx->d_metrics + 7), ctx->stream));
     HIP_TRY(hipMemcpyAsync(out8, ctx->d_metrics, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return LAFF_OK;
 }
 
-int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, double out7[7]) {
+int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, int base, int* ranks_out, double out7[7]) {
     CHECK_CTX(ctx);
     if (!rank1 || !out7) return fail(LAFF_E_ARG, "laff_rank_metrics: null argument");
     if (Nq < 1) return fail(LAFF_E_SHAPE, "laff_rank_metrics: Nq=%d", Nq);
@@ -608,7 +608,7 @@ int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, double out7[7]) {
         HIP_TRY(hipMalloc((void**)&ctx->d_metrics, 8 * sizeof(double)));
         HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
     }
-    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, ctx->d_metrics, (int*)(ctx->d_metrics + 7), ctx->stream));
+    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, (int*)(ctx->d_metrics + 7), ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_metrics, ctx->d_metrics, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (*(const int*)(ctx->h_metrics + 7)) return fail(LAFF_E_ARG, "laff_rank_metrics: ranks must be 1-based (found a value < 1)");

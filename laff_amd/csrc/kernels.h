@@ -106,8 +106,8 @@ hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int no
                             int precision, void* out, hipStream_t st);
 
 hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K, int bf16, int x3, float scale,
-                             const int* gt_col, int col0, float* s_gt, hipStream_t st);
-hipError_t launch_rank_metrics(const int* rank1, int n, double* out7, int* err, hipStream_t st);
+                             const int* gt_col, int col0, float* s_gt, int* zero_count, hipStream_t st);
+hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, int* err, hipStream_t st);
 hipError_t launch_gather_gt(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt,
                             hipStream_t st);
 hipError_t launch_rank_count(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, const float* s_gt,

@@ -104,10 +104,11 @@ __global__ __launch_bounds__(256) void v2t_count_kernel(const float* __restrict_
 template <bool BF16>
 __global__ __launch_bounds__(256) void row_dot_gt_kernel(const uint16_t* __restrict__ T, const uint16_t* __restrict__ V, int Nt,
                                                          int Nv, int K, int x3, float scale, const int* __restrict__ gt_col,
-                                                         int col0, float* __restrict__ s_gt) {
+                                                         int col0, float* __restrict__ s_gt, int* __restrict__ zero_count) {
     const int lane = threadIdx.x & 63;
     const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= Nt) return;
+    if (zero_count && lane == 0) zero_count[t] = 0;              // the fused count of laff_sim_gemm accumulates into this
     const int c = gt_col[t] - col0;
     if (c < 0 || c >= Nv) {
         if (lane == 0) s_gt[t] = -INFINITY;
@@ -147,12 +148,12 @@ __global__ __launch_bounds__(256) void row_dot_gt_kernel(const uint16_t* __restr
 }
 
 hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K, int bf16, int x3, float scale,
-                             const int* gt_col, int col0, float* s_gt, hipStream_t st) {
+                             const int* gt_col, int col0, float* s_gt, int* zero_count, hipStream_t st) {
     const unsigned grid = (unsigned)((Nt + 3) / 4);
     if (bf16)
-        hipLaunchKernelGGL((row_dot_gt_kernel<true>), dim3(grid), dim3(256), 0, st, (const uint16_t*)T, (const uint16_t*)V, Nt, Nv, K, x3, scale, gt_col, col0, s_gt);
+        hipLaunchKernelGGL((row_dot_gt_kernel<true>), dim3(grid), dim3(256), 0, st, (const uint16_t*)T, (const uint16_t*)V, Nt, Nv, K, x3, scale, gt_col, col0, s_gt, zero_count);
     else
-        hipLaunchKernelGGL((row_dot_gt_kernel<false>), dim3(grid), dim3(256), 0, st, (const uint16_t*)T, (const uint16_t*)V, Nt, Nv, K, x3, scale, gt_col, col0, s_gt);
+        hipLaunchKernelGGL((row_dot_gt_kernel<false>), dim3(grid), dim3(256), 0, st, (const uint16_t*)T, (const uint16_t*)V, Nt, Nv, K, x3, scale, gt_col, col0, s_gt, zero_count);
     return hipGetLastError();
 }
 
@@ -164,8 +165,9 @@ hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K
 // at C4) and 64 lanes adding to one LDS word serialise 64-deep -- a first radix version with plain bins took 72 us, a
 // 16-way value search without atomics 55 us (one workgroup = one CU: its VALU work does not spread), bisection 68 us.
 // One workgroup, ranks streamed from L2 each pass; all reductions of a phase share one barrier pair.
-__global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, double* __restrict__ out7,
-                                                            int* __restrict__ err) {
+// rank = r[i] + base (base = 1 turns the fused "better-scoring videos" counts into ranks); ranks_out, when given, receives them.
+__global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, int base, int* __restrict__ ranks_out,
+                                                            double* __restrict__ out7, int* __restrict__ err) {
     __shared__ double shd[16];
     __shared__ unsigned long long shl[16][4];
     __shared__ int shm[16][2];
@@ -179,7 +181,8 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     int mx = 0, mn = 0x7fffffff;
 #pragma unroll 4
     for (int i = tid; i < n; i += 1024) {
-        const int v = r[i];
+        const int v = r[i] + base;
+        if (ranks_out) ranks_out[i] = v;
         c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
         sum += (unsigned long long)(long long)v;
         // 1/v: fp32 reciprocal refined by two Newton steps in fp64 (relative error < 1e-16) instead of a full fp64 division
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
         __syncthreads();
 #pragma unroll 8
         for (int i = tid; i < n; i += 1024) {
-            const unsigned v = (unsigned)r[i];
+            const unsigned v = (unsigned)(r[i] + base);
             if ((v & mask) == prefix) atomicAdd(&hist[((v >> shift) & 255u) * 33 + rep], 1u);
         }
         __syncthreads();
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
         int below = 0;
 #pragma unroll 8
         for (int i = tid; i < n; i += 1024) {
-            const int v = r[i];
+            const int v = r[i] + base;
             if (v < med_lo) below = max(below, v);
         }
 #pragma unroll
@@ -278,8 +281,8 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     }
 }
 
-hipError_t launch_rank_metrics(const int* rank1, int n, double* out7, int* err, hipStream_t st) {
-    hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(1024), 0, st, rank1, n, out7, err);
+hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, int* err, hipStream_t st) {
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(1024), 0, st, r, n, base, ranks_out, out7, err);
     return hipGetLastError();
 }
 

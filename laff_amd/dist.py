@@ -95,13 +95,26 @@ class HipBackend:
         return ops.sim_gemm(T, V, heads=heads)
 
     def row_dot_gt(self, T, V, gt, heads, col0):
-        return ops.row_dot_gt(T, V, gt, heads, col0)
+        # the same launch clears the accumulator the fused count of sim_ranked adds into (no separate fill kernel)
+        self._count = torch.empty((T.N,), dtype=torch.int32, device=T.buf.device)
+        return ops.row_dot_gt(T, V, gt, heads, col0, zero_count=self._count)
 
     def sim_ranked(self, T, V, heads, gt, s_gt, col0, want_scores=True):
         """Score block + ground-truth rank counts in one GEMM launch (fused epilogue)."""
-        count = torch.zeros((T.N,), dtype=torch.int32, device=T.buf.device)
+        count = getattr(self, '_count', None)
+        if count is None or count.numel() != T.N:
+            count = torch.zeros((T.N,), dtype=torch.int32, device=T.buf.device)
+        self._count = None
         S = ops.sim_gemm(T, V, heads=heads, want_scores=want_scores, gt_col=gt, s_gt=s_gt, count=count, col0=col0)
         return S, count
+
+    def finish(self, count, out_pinned=None):
+        """ranks = count + 1 and the 7 metrics in one launch; returns (ranks, metrics or None when out_pinned is given)."""
+        ranks = torch.empty_like(count)
+        if out_pinned is not None:
+            ops.rank_metrics_async(count, out_pinned, base=1, ranks_out=ranks)
+            return ranks, None
+        return ranks, ops.rank_metrics(count, base=1, ranks_out=ranks)
 
     def metrics(self, ranks):
         return ops.rank_metrics(ranks)
@@ -215,15 +228,23 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
         if comm:
             dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
 
-        def finish():
-            ranks = count + 1
-            if metrics_out is not None:
-                compute.metrics_async(ranks, metrics_out)     # no host sync: the caller reads metrics_out after one
-            return ranks
-        ranks = run('finish' + finish_tag, finish)
-        mark('rank')
         metrics = None
-        if metrics_out is None and want_metrics:
-            metrics = compute.metrics(ranks)
+        if hasattr(compute, 'finish') and (metrics_out is not None or want_metrics):
+            # one launch: ranks = count + 1 and the metrics (no host sync when metrics_out is given)
+            if metrics_out is not None:
+                ranks = run('finish' + finish_tag, lambda: compute.finish(count, metrics_out)[0])
+            else:
+                ranks, metrics = compute.finish(count)
+            mark('rank')
+        else:
+            def finish():
+                ranks = count + 1
+                if metrics_out is not None:
+                    compute.metrics_async(ranks, metrics_out)     # no host sync: the caller reads metrics_out after one
+                return ranks
+            ranks = run('finish' + finish_tag, finish)
+            mark('rank')
+            if metrics_out is None and want_metrics:
+                metrics = compute.metrics(ranks)
         mark('metrics')
     return {'S_local': S_local, 'col0': v0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb}

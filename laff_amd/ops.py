@@ -447,14 +447,19 @@ def sim_gemm(T, V, heads=1, out=None, want_scores=True, gt_col=None, s_gt=None, 
     return S
 
 
-def row_dot_gt(T, V, gt_col, heads=1, col0=0):
-    """s_gt[t] = <T[t], V[gt[t]-col0]> / (heads * prescale^2) on the packed operands; -inf outside this shard."""
+def row_dot_gt(T, V, gt_col, heads=1, col0=0, zero_count=None):
+    """s_gt[t] = <T[t], V[gt[t]-col0]> / (heads * prescale^2) on the packed operands; -inf outside this shard.
+    zero_count: optional int32 (Nt,) tensor cleared by the same launch (the accumulator of the fused count)."""
     _dev(gt_col, 'gt_col', torch.int32)
+    if zero_count is not None:
+        _dev(zero_count, 'zero_count', torch.int32)
+        if zero_count.numel() != T.N or not zero_count.is_contiguous():
+            raise ValueError('zero_count must be a contiguous int32 vector of %d' % T.N)
     out = torch.empty((T.N,), device=T.buf.device, dtype=torch.float32)
     scale = 1.0 / (heads * T.prescale * V.prescale)
     lib, h = _context(T.buf.device)
     _call('row_dot_gt', lib.laff_row_dot_gt, h, _ptr(T.buf), _ptr(V.buf), T.N, V.N, T.K, scale, PREC[T.precision], _ptr(gt_col),
-          col0, _ptr(out))
+          col0, _ptr(out), _ptr(zero_count))
     return out
 
 
@@ -503,16 +508,25 @@ def v2t_count(S, grp_off, grp_idx, max_group):
     return count
 
 
-def rank_metrics(rank1):
-    """(r1, r5, r10, medr, meanr, mir, mAP) from 1-based int32 device ranks; synchronises the stream."""
+def _ranks_out(r, ranks_out):
+    if ranks_out is not None:
+        _dev(ranks_out, 'ranks_out', torch.int32)
+        if ranks_out.numel() != r.numel() or not ranks_out.is_contiguous():
+            raise ValueError('ranks_out must be a contiguous int32 vector of %d' % r.numel())
+    return ranks_out
+
+
+def rank_metrics(rank1, base=0, ranks_out=None):
+    """(r1, r5, r10, medr, meanr, mir, mAP) from int32 device values r with rank = r + base (1-based ranks: base 0; counts of
+    better-scoring videos: base 1); ranks_out optionally receives the ranks.  Synchronises the stream."""
     _dev(rank1, 'rank1', torch.int32)
     out = (C.c_double * 7)()
     lib, h = _context(rank1.device)
-    check(lib.laff_rank_metrics(h, _ptr(rank1.contiguous()), rank1.numel(), out))
+    check(lib.laff_rank_metrics(h, _ptr(rank1.contiguous()), rank1.numel(), int(base), _ptr(_ranks_out(rank1, ranks_out)), out))
     return tuple(out)
 
 
-def rank_metrics_async(rank1, out_pinned):
+def rank_metrics_async(rank1, out_pinned, base=0, ranks_out=None):
     """Launch the metrics reduction and the 64-byte D2H copy without synchronising (HIP-graph capturable).
     out_pinned: pinned CPU float64 tensor of 8; after a stream sync [:7] are the metrics, [7] != 0 flags a rank < 1."""
     _dev(rank1, 'rank1', torch.int32)
@@ -523,7 +537,8 @@ def rank_metrics_async(rank1, out_pinned):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError('call ops.ctx_prepare_metrics(device) before capturing a graph (it allocates scratch)')
         ctx_prepare_metrics(rank1.device)
-    check(lib.laff_rank_metrics_async(h, _ptr(rank1.contiguous()), rank1.numel(), C.c_void_p(out_pinned.data_ptr())))
+    check(lib.laff_rank_metrics_async(h, _ptr(rank1.contiguous()), rank1.numel(), int(base), _ptr(_ranks_out(rank1, ranks_out)),
+                                      C.c_void_p(out_pinned.data_ptr())))
 
 
 def ctx_prepare_metrics(device):
@@ -533,5 +548,5 @@ def ctx_prepare_metrics(device):
     if key not in _ctx:
         r = torch.ones(1, dtype=torch.int32, device=device)
         out = (C.c_double * 7)()
-        check(lib.laff_rank_metrics(h, _ptr(r), 1, out))
+        check(lib.laff_rank_metrics(h, _ptr(r), 1, 0, None, out))
         _ctx[key] = True

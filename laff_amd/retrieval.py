@@ -42,9 +42,12 @@ def evaluate(model, vis_feats, txt_feats, gt, precision='fp16', write_scores=Tru
             s_gt = ops.gather_gt(S, gt)
             count = ops.rank_count(S, gt, s_gt)
         else:
-            s_gt = ops.row_dot_gt(T, V, gt, heads)
-            count = torch.zeros((T.N,), dtype=torch.int32, device=gt.device)
+            count = torch.empty((T.N,), dtype=torch.int32, device=gt.device)
+            s_gt = ops.row_dot_gt(T, V, gt, heads, zero_count=count)
             S = ops.sim_gemm(T, V, heads=heads, want_scores=write_scores, gt_col=gt, s_gt=s_gt, count=count)
-        ranks = count + 1
-        metrics = ops.rank_metrics(ranks) if want_metrics else None
+        if want_metrics:
+            ranks = torch.empty_like(count)
+            metrics = ops.rank_metrics(count, base=1, ranks_out=ranks)
+        else:
+            ranks, metrics = count + 1, None
     return RetrievalResult(S, ranks, metrics, vis_emb, txt_emb)
