@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 8
+#define LAFF_ABI_VERSION 9
 
 enum {
     LAFF_OK = 0,
@@ -158,6 +158,15 @@ typedef struct {
     const float* scale;   /* [H*d] or NULL (=1) */
     const float* shift;   /* [H*d] or NULL (=0) */
     int act;              /* LAFF_ACT_* applied to src before the affine (0 = none) */
+    /* GATHER plane (src == NULL, wt != NULL): a sparse feature through its FC without materialising the projected plane --
+     * value[n, c] = sum_j values[j] * wt[indices[j], c] + bias[c] over the CSR row n (the arithmetic of laff_fc_gather_act_bn),
+     * then act and the affine as above.  d <= 512 per head, never tiled. */
+    const int* indptr;    /* [N+1] */
+    const int* indices;   /* [nnz] */
+    const float* values;  /* [nnz] or NULL (all ones) */
+    const float* wt;      /* [dk, ldwt] = W^T */
+    int ldwt, dk;
+    const float* bias;    /* [H*d] or NULL */
 } laff_plane;
 
 /* E[N,H,d] (unit L2 norm per (n,h) unless JUST_AVERAGE).  w [H,d], b [H], gw [H] device arrays.

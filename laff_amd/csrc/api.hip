@@ -409,18 +409,31 @@ int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int 
     if (!aligned16(E) || (w && !aligned16(w))) return fail(LAFF_E_ALIGN, "laff_fuse: E/w must be 16-byte aligned");
     const bool nosplit = flags & LAFF_ATT_NO_SPLIT_HEAD;
     laff::FuseArgs a{};
+    bool any_gather = false;
     for (int l = 0; l < L; ++l) {
         const laff_plane& p = planes[l];
-        if (!p.src) return fail(LAFF_E_ARG, "laff_fuse: plane %d has null src", l);
         if ((p.scale == nullptr) != (p.shift == nullptr)) return fail(LAFF_E_ARG, "laff_fuse: plane %d scale/shift must come together", l);
+        if (p.act < LAFF_ACT_NONE || p.act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fuse: plane %d bad act %d", l, p.act);
+        if (p.scale && (!aligned16(p.scale) || !aligned16(p.shift))) return fail(LAFF_E_ALIGN, "laff_fuse: plane %d affine not 16-byte aligned", l);
+        if (!p.src && p.wt) {                          // gather plane
+            if (!p.indptr || !p.indices) return fail(LAFF_E_ARG, "laff_fuse: gather plane %d needs indptr / indices", l);
+            if (p.tile || nosplit || d > 512) return fail(LAFF_E_UNSUPPORTED, "laff_fuse: gather plane %d needs split heads of d <= 512, not tiled", l);
+            if (p.dk < 1 || p.ldwt < H * d || (p.ldwt & 3)) return fail(LAFF_E_SHAPE, "laff_fuse: gather plane %d: dk=%d ldwt=%d (need >= %d, multiple of 4)", l, p.dk, p.ldwt, H * d);
+            if (!aligned16(p.wt) || (p.bias && !aligned16(p.bias))) return fail(LAFF_E_ALIGN, "laff_fuse: gather plane %d not 16-byte aligned", l);
+            a.g_indptr[l] = p.indptr; a.g_indices[l] = p.indices; a.g_values[l] = p.values; a.g_wt[l] = p.wt; a.g_bias[l] = p.bias;
+            a.g_ldwt[l] = p.ldwt; a.g_dk[l] = p.dk;
+            a.scale[l] = p.scale; a.shift[l] = p.shift; a.act[l] = p.act;
+            any_gather = true;
+            continue;
+        }
+        if (!p.src) return fail(LAFF_E_ARG, "laff_fuse: plane %d has null src", l);
         if (p.tile && nosplit) return fail(LAFF_E_UNSUPPORTED, "laff_fuse: tiled plane with NO_SPLIT_HEAD");
         const int need = p.tile ? d : (nosplit ? d : H * d);
         if (p.ld < need || (p.ld & 3)) return fail(LAFF_E_SHAPE, "laff_fuse: plane %d ld=%d (need >= %d, multiple of 4)", l, p.ld, need);
-        if (!aligned16(p.src) || (p.scale && (!aligned16(p.scale) || !aligned16(p.shift))))
-            return fail(LAFF_E_ALIGN, "laff_fuse: plane %d not 16-byte aligned", l);
-        if (p.act < LAFF_ACT_NONE || p.act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fuse: plane %d bad act %d", l, p.act);
+        if (!aligned16(p.src)) return fail(LAFF_E_ALIGN, "laff_fuse: plane %d not 16-byte aligned", l);
         a.src[l] = p.src; a.ld[l] = p.ld; a.tile[l] = p.tile; a.scale[l] = p.scale; a.shift[l] = p.shift; a.act[l] = p.act;
     }
+    a.head_major = any_gather ? 1 : 0;
     if (N == 0) return LAFF_OK;
     a.L = L; a.N = N; a.H = H; a.d = d; a.head_stride = nosplit ? 0 : d;
     a.w = w; a.b = b; a.gw = gw; a.flags = flags; a.E = E; a.attn_w = attn_w;

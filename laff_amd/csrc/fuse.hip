@@ -62,6 +62,63 @@ __device__ __forceinline__ float4 load_plane(const FuseArgs& a, int l, long n, i
     return v;
 }
 
+// gather plane (sparse feature through its FC, fc_gather_kernel's arithmetic inside the fuse launch): the projected plane is
+// never written to / re-read from HBM.  The caption's ids arrive with one coalesced load per 64 and are broadcast with
+// v_readlane; all NCH column chunks of the (row, head) are accumulated in the same pass over the ids.
+template <int NCH>
+__device__ __forceinline__ void load_gather_plane(const FuseArgs& a, int l, long n, int h, int lane, int d, float4 (&out)[NCH]) {
+    const int beg = a.g_indptr[l][n], end = a.g_indptr[l][n + 1];
+    const float* wt = a.g_wt[l];
+    const long ldwt = a.g_ldwt[l];
+    const int dk = a.g_dk[l];
+    const int cbase = h * a.head_stride;                         // gather planes are never tiled
+    float4 acc[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) acc[j] = make_float4(0, 0, 0, 0);
+    for (int p0 = beg; p0 < end; p0 += 64) {
+        const int cnt = min(64, end - p0);
+        int wi = 0;
+        float vi = 0.0f;
+        if (lane < cnt) {
+            wi = a.g_indices[l][p0 + lane];
+            vi = a.g_values[l] ? a.g_values[l][p0 + lane] : 1.0f;
+            if (wi < 0 || wi >= dk) { wi = 0; vi = 0.0f; }
+        }
+        for (int q = 0; q < cnt; q += 4) {                       // lanes >= cnt hold (row 0, weight 0)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = __builtin_amdgcn_readlane(wi, q + u);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vi), q + u));
+                const float* row = wt + (long)w * ldwt + cbase;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const int col = j * 256 + lane * 4;
+                    if (col < d) acc[j] = fma4(*(const float4*)(row + col), v, acc[j]);
+                }
+            }
+        }
+    }
+    const int act = a.act[l];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int col = j * 256 + lane * 4;
+        float4 v = acc[j];
+        if (col < d) {
+            const int c = cbase + col;
+            if (a.g_bias[l]) v = add4(v, *(const float4*)(a.g_bias[l] + c));
+            if (act == LAFF_ACT_TANH) v = make_float4(plane_tanh(v.x), plane_tanh(v.y), plane_tanh(v.z), plane_tanh(v.w));
+            else if (act == LAFF_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            else if (act == LAFF_ACT_SIGMOID) v = make_float4(plane_sigmoid(v.x), plane_sigmoid(v.y), plane_sigmoid(v.z), plane_sigmoid(v.w));
+            if (a.scale[l]) {
+                const float4 s = *(const float4*)(a.scale[l] + c);
+                const float4 t = *(const float4*)(a.shift[l] + c);
+                v = make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
+            }
+        }
+        out[j] = v;
+    }
+}
+
 __device__ __forceinline__ void store16x4(void* base, long idx, float4 v, float scale, int bf16) {
     if (bf16) {
         typedef __bf16 b4 __attribute__((ext_vector_type(4)));
@@ -95,10 +152,19 @@ __device__ __forceinline__ void softmax_L(float (&lg)[L]) {
 template <int L, int NCH>
 __global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
     const int lane = threadIdx.x & 63;
-    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (long)a.N * a.H) return;
-    const long n = item / a.H;
-    const int h = (int)(item - n * a.H);
+    long n;
+    int h;
+    if (a.head_major) {                                          // gather planes: all four waves of a block share the head
+        h = (int)(blockIdx.x % (unsigned)a.H);
+        n = (long)(blockIdx.x / (unsigned)a.H) * 4 + (threadIdx.x >> 6);
+        if (n >= a.N) return;
+    } else {
+        const long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (it >= (long)a.N * a.H) return;
+        n = it / a.H;
+        h = (int)(it - n * a.H);
+    }
+    const long item = n * a.H + h;
     const int d = a.d;
 
     float4 x[L][NCH];
@@ -109,8 +175,12 @@ __global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
         const bool ok = col < d;
         wv[j] = (ok && a.w) ? *(const float4*)(a.w + (long)h * d + col) : make_float4(0, 0, 0, 0);
 #pragma unroll
-        for (int l = 0; l < L; ++l) x[l][j] = ok ? load_plane(a, l, n, h, col) : make_float4(0, 0, 0, 0);
+        for (int l = 0; l < L; ++l)
+            if (!a.g_wt[l]) x[l][j] = ok ? load_plane(a, l, n, h, col) : make_float4(0, 0, 0, 0);
     }
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+        if (a.g_wt[l]) load_gather_plane<NCH>(a, l, n, h, lane, d, x[l]);      // wave-uniform branch
     if (a.flags & LAFF_ATT_L2NORM_EACH_HEAD) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
@@ -258,7 +328,7 @@ __global__ __launch_bounds__(256) void fuse_stream_kernel(FuseArgs a) {
 template <int L>
 static hipError_t launch_fuse_L(const FuseArgs& a, hipStream_t st) {
     const long items = (long)a.N * a.H;
-    const unsigned grid = (unsigned)((items + 3) / 4);
+    const unsigned grid = a.head_major ? (unsigned)(((long)a.N + 3) / 4 * a.H) : (unsigned)((items + 3) / 4);
     if (a.d <= 256)
         hipLaunchKernelGGL((fuse_reg_kernel<L, 1>), dim3(grid), dim3(256), 0, st, a);
     else if (a.d <= 512)

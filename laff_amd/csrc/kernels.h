@@ -60,6 +60,14 @@ struct FuseArgs {
     int ld[MAX_L];
     int tile[MAX_L];
     int act[MAX_L];       // LAFF_ACT_* applied to the plane before its affine
+    // gather planes (src == null): plane value = sum_j values_j * Wt[indices_j, column] + bias[column]  (sparse bag-of-words FC)
+    const int* g_indptr[MAX_L];
+    const int* g_indices[MAX_L];
+    const float* g_values[MAX_L];     // null = all ones
+    const float* g_wt[MAX_L];         // [Dk, g_ldwt], non-null marks a gather plane
+    const float* g_bias[MAX_L];
+    int g_ldwt[MAX_L], g_dk[MAX_L];
+    int head_major;       // block -> (head = b % H, 4 rows): with H == 8 every XCD gathers from its own 512-column slice of Wt
     int L, N, H, d;
     int head_stride;      // d (split heads) or 0 (every head sees all columns)
     const float* w;       // [H, d]

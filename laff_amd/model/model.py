@@ -32,6 +32,8 @@ float16 = False
 #: arithmetic of the FC projections: 'fp32' (v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 FMA chain) or 'fp16x3'
 #: (exact fp16 hi/lo operand split, 3 MFMA passes at the fp16 rate, ~2^-22 relative per product)
 FC_PRECISION = 'fp32'
+#: tower path: sparse (bag-of-words) features are gathered inside the fuse launch (LAFF_GATHER_IN_FUSE=0: separate FC launch)
+GATHER_IN_FUSE = os.environ.get('LAFF_GATHER_IN_FUSE', '1') != '0'
 #: fp16x3 only: split the inputs inside the GEMM instead of materialising their hi/lo planes (LAFF_FUSED_SPLIT=0 disables)
 FUSED_SPLIT = os.environ.get('LAFF_FUSED_SPLIT', '1') != '0'
 
@@ -165,15 +167,18 @@ class TransformNet(nn.Module):
             self._w_split = (key, ops.split_rows(w.detach()))
         return self._w_split[1]
 
-    def plane(self, x, heads=1, extra_shift=None, pending=None):
+    def plane(self, x, heads=1, extra_shift=None, pending=None, head_dim=None):
         """(src, tile, scale, shift) for laff_fuse.  With an FC the projection either runs now or, when `pending`
         (a list) is given, is appended to it so that the caller launches all features' GEMMs as one grouped kernel."""
         _eval_only(self)
         scale, shift = self.bn_affine(extra_shift)
         if self.fc1 is not None and x.layout == torch.sparse_csr:
             # sparse feature (bag-of-words): gather-sum of columns of W instead of a dense N x |vocab| x D GEMM
-            y = ops.fc_gather_act_bn(x.to(device), self.weight_t(), self.fc1.bias.detach() if self.fc1.bias is not None else None,
-                                     scale, shift, self.activation_name)
+            bias = self.fc1.bias.detach() if self.fc1.bias is not None else None
+            if pending is not None and GATHER_IN_FUSE and head_dim is not None and head_dim <= 512:
+                # tower path: the gather runs INSIDE the fuse launch (the projected plane is never written / re-read)
+                return (None, False, scale, shift, self.activation_name, (x.to(device), self.weight_t(), bias))
+            y = ops.fc_gather_act_bn(x.to(device), self.weight_t(), bias, scale, shift, self.activation_name)
             return (y, False, None, None)
         x = to_device_and_float16(x)
         if self.fc1 is not None:
@@ -388,7 +393,9 @@ class MultiScaleTxtEncoderAttention(nn.Module):
             feats = getattr(self.encoder, name)(caption_feat_dict, task3=task3)['text_features']
             h = heads if name in self.opt.txt_no_transform else 1
             planes.append(getattr(self.transform_layer, name + '_transform').plane(
-                feats, h, None if expert is None else expert[i], pending))
+                feats, h, None if expert is None else expert[i], pending, head_dim=self.opt.txt_fc_layers[1] // heads
+                if type(self.attention_layer).__name__ == 'Multi_head_MyApply_Attention' and
+                self.attention_layer.split_head else None))
         return lambda: _fuse(self.attention_layer, planes, heads)
 
     def forward(self, caption_feat_dict, visual_emb=None, task3=False):

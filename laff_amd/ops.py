@@ -316,24 +316,43 @@ def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=N
     packed_precision ('fp16' | 'bf16'): also emit the similarity operand in the same launch; returned last."""
     L = len(planes)
     arr = (Plane * L)()
-    N = planes[0][0].shape[0]
+    first = planes[0]
+    N = (first[5][0] if (len(first) > 5 and first[5] is not None) else first[0]).shape[0]
     keep = []
     for i, pl in enumerate(planes):
         src, tile, scale, shift = pl[:4]
         act = pl[4] if len(pl) > 4 else None
+        gather = pl[5] if len(pl) > 5 else None
+        for t in (scale, shift):
+            if t is not None:
+                _dev(t, 'plane affine')
+        sp, tp = (scale.data_ptr() if scale is not None else None), (shift.data_ptr() if shift is not None else None)
+        if gather is not None:
+            # (csr, weight_t, bias): a sparse feature through its FC, gathered inside the fuse launch
+            csr, wt, bias = gather
+            if csr.layout != torch.sparse_csr or csr.shape[0] != N:
+                raise ValueError('gather plane %d must be a CSR matrix with %d rows' % (i, N))
+            wt, ldwt = _rows(wt, 'weight_t')
+            if wt.shape[0] != csr.shape[1] or wt.shape[1] != H * d or tile or (flags & ATT_NO_SPLIT_HEAD) or d > 512:
+                raise ValueError('gather plane %d: weight_t must be (%d, %d), split heads of d <= 512' % (i, csr.shape[1], H * d))
+            crow = csr.crow_indices().to(torch.int32).contiguous()
+            col = csr.col_indices().to(torch.int32).contiguous()
+            val = csr.values().to(torch.float32).contiguous()
+            if bias is not None:
+                _dev(bias, 'bias')
+            arr[i] = Plane(None, 0, 0, sp, tp, ACT[act], crow.data_ptr(), col.data_ptr(), val.data_ptr(), wt.data_ptr(), ldwt,
+                           csr.shape[1], bias.data_ptr() if bias is not None else None)
+            keep.append((crow, col, val, wt, bias, scale, shift))
+            continue
         src, ld = _rows(src, 'plane %d' % i)
         if src.shape[0] != N:
             raise ValueError('plane %d has %d rows, expected %d' % (i, src.shape[0], N))
         need = d if (tile or (flags & ATT_NO_SPLIT_HEAD)) else H * d
         if src.shape[1] != need:
             raise ValueError('plane %d has %d columns, expected %d' % (i, src.shape[1], need))
-        for t in (scale, shift):
-            if t is not None:
-                _dev(t, 'plane affine')
-        arr[i] = Plane(src.data_ptr(), ld, 1 if tile else 0, scale.data_ptr() if scale is not None else None,
-                       shift.data_ptr() if shift is not None else None, ACT[act])
+        arr[i] = Plane(src.data_ptr(), ld, 1 if tile else 0, sp, tp, ACT[act], None, None, None, None, 0, 0, None)
         keep.append((src, scale, shift))
-    dev = planes[0][0].device
+    dev = (first[5][1] if (len(first) > 5 and first[5] is not None) else first[0]).device
     E = torch.empty((N, H, d), device=dev, dtype=torch.float32)
     aw = torch.empty((N, H, L), device=dev, dtype=torch.float32) if return_weights else None
     for t, nm in ((w, 'w'), (b, 'b'), (gw, 'gw')):

@@ -621,3 +621,32 @@ def test_frame_fuse_grouped_equals_per_feature_launches():
         grouped = ops.frame_fuse_grouped(frames, ld, params, flags)
         for f, (w, b, gw), v in zip(frames, params, grouped):
             assert torch.equal(v, ops.frame_fuse(f, ld, w, b, gw, flags))
+
+
+@pytest.mark.parametrize('H,d,act', [(8, 512, 'tanh'), (1, 64, None), (2, 256, 'relu'), (4, 128, 'sigmoid')])
+def test_fuse_gather_plane_equals_separate_gather_fc(H, d, act):
+    """A sparse feature through its FC as a GATHER plane of laff_fuse == laff_fc_gather_act_bn followed by a plain plane."""
+    from laff_amd import ops
+    g = rnd(H * d)
+    N, Dk, D = 75, 300, H * d
+    crow, col, val, dense = _random_csr(g, N, Dk, 20)
+    W = (g.normal(0, 1, (D, Dk)) / 4).astype(np.float32)
+    bias = g.normal(0, 0.1, D).astype(np.float32)
+    sc = g.uniform(0.5, 1.5, D).astype(np.float32)
+    sh = g.normal(0, 0.1, D).astype(np.float32)
+    other = np.tanh(g.normal(0, 1, (N, D))).astype(np.float32)
+    clip = g.normal(0, 1, (N, d)).astype(np.float32)
+    w, b, gw = dev(g.normal(0, 0.2, (H, d)).astype(np.float32)), dev(g.normal(0, 0.1, H).astype(np.float32)), dev(np.full(H, 0.6, np.float32))
+    csr = torch.sparse_csr_tensor(dev(crow, torch.int32), dev(col, torch.int32), dev(val), size=(N, Dk))
+    wt = dev(np.ascontiguousarray(W.T))
+    flags = ops.attention_flags(with_ave=True)
+    y = ops.fc_gather_act_bn(csr, wt, dev(bias), dev(sc), dev(sh), act)
+    base = [(dev(other), False, None, None), (dev(clip), True, dev(sc), dev(sh))]
+    E_ref = ops.fuse([(y, False, None, None)] + base, H, d, w, b, gw, flags)
+    E_gat = ops.fuse([(None, False, dev(sc), dev(sh), act, (csr, wt, dev(bias)))] + base, H, d, w, b, gw, flags)
+    assert maxdiff(E_gat, E_ref) <= 2e-6
+    # against the oracle on the densified input
+    ref_plane = O.transform_net(dense, W, bias, act, None) * sc + sh
+    ref = O.multi_head_attention(np.stack([ref_plane, other, np.tile(clip, (1, H)) * sc + sh], axis=1), w.cpu().numpy(), b.cpu().numpy(),
+                                 gw.cpu().numpy(), H, True, False)
+    assert maxdiff(E_gat, ref) <= 5e-6
