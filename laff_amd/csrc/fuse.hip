@@ -48,7 +48,10 @@ __device__ __forceinline__ float plane_sigmoid(float x) {
 // x_l[n,h,col..col+3] with the plane's activation, tiling and folded affine applied
 __device__ __forceinline__ float4 load_plane(const FuseArgs& a, int l, long n, int h, int col) {
     const int srccol = a.tile[l] ? col : h * a.head_stride + col;
-    float4 v = *(const float4*)(a.src[l] + n * a.ld[l] + srccol);
+    typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+    // a projected plane is read exactly once: stream it past the L2 lines that hold the attention / BN vectors and Wt slices
+    const nt_f32x4 nv = __builtin_nontemporal_load((const nt_f32x4*)(a.src[l] + n * a.ld[l] + srccol));
+    float4 v = make_float4(nv.x, nv.y, nv.z, nv.w);
     const int act = a.act[l];                                   // wave-uniform
     if (act == LAFF_ACT_TANH) v = make_float4(plane_tanh(v.x), plane_tanh(v.y), plane_tanh(v.z), plane_tanh(v.w));
     else if (act == LAFF_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
@@ -241,7 +244,8 @@ __global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
     for (int j = 0; j < NCH; ++j) {
         const int col = j * 256 + lane * 4;
         if (col < d) {
-            *(float4*)(a.E + item * d + col) = g[j];
+            typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(nt_f32x4{g[j].x, g[j].y, g[j].z, g[j].w}, (nt_f32x4*)(a.E + item * d + col));
             if (a.E16) store16x4(a.E16, item * d + col, g[j], a.e16_scale, a.e16_bf16);
         }
     }
