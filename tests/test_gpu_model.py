@@ -36,6 +36,13 @@ def test_laff_towers_golden(golden):
         assert maxdiff(te, g[k + '/txt_emb']) <= 5e-6
         assert maxdiff(model.get_txt2vis_matrix(te, ve, precision='fp16x3'), g[k + '/scores']) <= 5e-6
         assert maxdiff(model.get_txt2vis_matrix(te, ve), g[k + '/scores']) <= 1e-4     # default fp16 operands
+        if 'bow_encoding' in cap:
+            # the same bag-of-words feature handed over as a CSR matrix: gathered inside the fuse launch (gather plane)
+            dense = cap['bow_encoding'].to(DEV).float()
+            sp = dense.to_sparse_csr()
+            cap_sp = dict(cap, bow_encoding=torch.sparse_csr_tensor(sp.crow_indices().to(torch.int32), sp.col_indices().to(torch.int32),
+                                                                     sp.values(), size=sp.shape))
+            assert maxdiff(model.txt_net(cap_sp), g[k + '/txt_emb']) <= 5e-6
         assert vis_in['X3D_L'].is_cuda       # in-place device move of the caller's dict, like the reference
         assert maxdiff(model.encode_video({n: t(g[k + '/vis/' + n]) for n in c['vid_dims']}), g[k + '/vis_emb']) <= 5e-6
 
