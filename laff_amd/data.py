@@ -27,6 +27,52 @@ def write_bigfile(datadir, ids, matrix):
         f.write('%d %d' % matrix.shape)
 
 
+class NpyFeatures:
+    """Features kept as a numpy file instead of a BigFile directory -- the two forms the reference reads: a pickled
+    `{id: vector}` dict (`np.load(path, allow_pickle=True).item()`, trainer.py:144-148) or a plain (N, D) array next to an id list.
+    Exposes the part of the BigFile surface the bulk loaders use (`names`, `ndims`, `nr_of_images`, `shape()`, `read_matrix`,
+    `read`, `read_one`), so it can stand wherever a BigFile is expected in BulkVisLoader / BulkTxtLoader."""
+
+    def __init__(self, path_or_array, ids=None):
+        obj = np.load(path_or_array, allow_pickle=True) if isinstance(path_or_array, str) else path_or_array
+        if isinstance(obj, np.ndarray) and obj.dtype == object and obj.shape == ():
+            obj = obj.item()
+        if isinstance(obj, dict):
+            self.names = list(obj.keys())
+            self._m = np.ascontiguousarray(np.stack([np.asarray(obj[k], dtype=np.float32).reshape(-1) for k in self.names]))
+        else:
+            if ids is None:
+                raise ValueError('a plain (N, D) array needs the list of ids of its rows')
+            self.names = list(ids)
+            self._m = np.ascontiguousarray(np.asarray(obj, dtype=np.float32))
+            if self._m.ndim != 2 or self._m.shape[0] != len(self.names):
+                raise ValueError('array of shape %s does not match %d ids' % (self._m.shape, len(self.names)))
+        self.name2index = dict(zip(self.names, range(len(self.names))))
+        self.nr_of_images, self.ndims = self._m.shape
+
+    def _matrix(self):
+        return self._m
+
+    def shape(self):
+        return [self.nr_of_images, self.ndims]
+
+    def read_matrix(self, names, out=None):
+        idx = np.fromiter((self.name2index[n] for n in names), dtype=np.int64, count=len(names))
+        if out is None:
+            out = np.empty((len(idx), self.ndims), dtype=np.float32)
+        np.take(self._m, idx, axis=0, out=out)
+        return out
+
+    def read(self, requested, isname=True):
+        """BigFile.read semantics (bigfile.py:187-213): duplicates removed, unknown ids dropped, rows in storage order."""
+        idx = sorted({self.name2index[r] for r in requested if r in self.name2index} if isname else set(requested))
+        return [self.names[i] for i in idx], [self._m[i].tolist() for i in idx]
+
+    def read_one(self, name):
+        renamed, vectors = self.read([name])
+        return vectors[0]
+
+
 class _Dataset:
     def __init__(self, n, captions=None):
         self.length = n

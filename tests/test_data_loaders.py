@@ -94,3 +94,25 @@ def test_predict_from_disk_equals_device_pipeline(tmp_path):
     assert float(np.abs(scores - res.S.cpu().numpy()).max()) <= 2e-4         # batched vs whole-matrix towers, fp16 GEMM
     t2v, v2t = predictor.retrieval_metrics(torch.from_numpy(scores).to(dev), txt_ids, out_vis)
     assert abs(t2v[0] - res.metrics[0]) <= 0.5 and t2v[3] == res.metrics[3]
+
+
+def test_npy_features_stand_in_for_a_bigfile(tmp_path):
+    """The numpy forms the reference reads (pickled {id: vector} dict, trainer.py:144-148; plain array + ids) behind the BigFile
+    surface of the bulk loaders."""
+    from laff_amd.data import BulkTxtLoader, NpyFeatures
+    g = np.random.default_rng(3)
+    ids = ['cap%d' % i for i in range(11)]
+    mat = g.normal(0, 1, (11, 6)).astype(np.float32)
+    path = str(tmp_path / 'feat.npy')
+    np.save(path, {k: v for k, v in zip(ids, mat)}, allow_pickle=True)
+    for src in (NpyFeatures(path), NpyFeatures(mat, ids)):
+        assert src.shape() == [11, 6] and src.ndims == 6 and src.names == ids
+        assert np.array_equal(src.read_matrix(['cap3', 'cap0', 'cap3']), mat[[3, 0, 3]])
+        names, vecs = src.read(['cap9', 'nope', 'cap2', 'cap9'])
+        assert names == ['cap2', 'cap9'] and np.allclose(vecs, mat[[2, 9]])
+        assert np.allclose(src.read_one('cap5'), mat[5])
+        with pytest.raises(IndexError):
+            src.read_one('missing')
+    loader = BulkTxtLoader([(i, 'a caption') for i in ids], {'CLIP_encoding': NpyFeatures(path)}, batch_size=4, device=None)
+    got = np.concatenate([cap['CLIP_encoding'].numpy() for cap, _, _ in loader])
+    assert np.array_equal(got, mat) and len(loader) == 3
