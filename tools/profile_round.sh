@@ -14,6 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- $BENCH > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- $BENCH > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- $BENCH > "$OUT/write.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT -d "$OUT/mfma" -o m --output-format csv -- $BENCH > "$OUT/mfma.log" 2>&1
 cd "$ROOT"
 # summaries go to gpurun_out/ (the only directory gpurun copies back); `cp gpurun_out/prof_<tag>/summary/* profiles/` commits them
 S=$OUT/summary
@@ -21,6 +22,7 @@ mkdir -p "$S"
 python3 tools/rocprof_summary.py "$OUT/trace" --out $S/${TAG}_bench_kernel_trace.txt
 python3 tools/rocprof_summary.py "$OUT/fetch" --out $S/${TAG}_bench_pmc_fetch.txt
 python3 tools/rocprof_summary.py "$OUT/write" --out $S/${TAG}_bench_pmc_write.txt
+python3 tools/mfma_util.py "$OUT/mfma" > $S/${TAG}_bench_pmc_mfma.txt
 python3 tools/make_traffic.py "$OUT/fetch" "$OUT/write" $S/${TAG}_traffic.json > /dev/null
 cp $S/${TAG}_traffic.json profiles/${TAG}_traffic.json          # bench.py reads roofline.traffic from here
 python3 tools/timeline.py "$OUT/trace" > $S/${TAG}_bench_timeline.txt || true
