@@ -147,6 +147,9 @@ def main():
     ap.add_argument('--fc-precision', default='fp16x3', help="FC projections: fp32 (fp32 MFMA) | fp16x3 (exact fp16 hi/lo split)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of HIP-graph replays')
+    ap.add_argument('--shard', default='video', choices=['video', 'text'],
+                    help="N > 1 decomposition: 'video' (BASELINE.json: video-row shards, all-gather of the text operand) or 'text' "
+                         "(text-row shards, all-gather of the smaller video operand, no all-reduce)")
     ap.add_argument('--force-dist', action='store_true', help='run the N > 1 code path (collectives included) on a 1-rank group')
     ap.add_argument('--profile-steps', type=int, default=5, help='eager steps (after the timed region) for per-kernel events')
     ap.add_argument('--seed', type=int, default=1237)
@@ -164,7 +167,7 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     from laff_amd import synth
-    from laff_amd.dist import HipBackend, evaluate_sharded, shard_bounds
+    from laff_amd.dist import HipBackend, evaluate_sharded, evaluate_sharded_by_text, shard_bounds
     import laff_amd.model.model as M
     M.FC_PRECISION = args.fc_precision
     Nt, Nv, heads, d, frames = synth.WORKLOADS[args.workload]
@@ -193,6 +196,10 @@ def main():
         timer.enabled = timed
         prof.enabled = timed
         timer.start()
+        if args.shard == 'text' and distributed:
+            return evaluate_sharded_by_text(backend, vis_l, txt_l, gt, Nt, Nv, heads,
+                                            metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
+                                            force_collectives=force_dist, finish_tag=str(slot))
         return evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer,
                                 metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
                                 force_collectives=force_dist, finish_tag=str(slot))
@@ -326,8 +333,9 @@ def main():
             'gather_gt': ('hbm', 8.0 * Nt, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'row_dot_gt': ('hbm', 2.0 * 2 * Nt * K, HBM_PEAK_GBS, 1e9, 'GB/s'),
         }
-        sim_bytes = 4.0 * Nt * nvl + 2.0 * (Nt + nvl) * K                  # fp32 S written once + 16-bit operands read once
-        sim_flops = 2.0 * K * Nt * nvl * x3
+        sim_r, sim_c = (ntl, Nv) if (args.shard == 'text' and distributed) else (Nt, nvl)
+        sim_bytes = 4.0 * sim_r * sim_c + 2.0 * (sim_r + sim_c) * K              # fp32 S written once + 16-bit operands read once
+        sim_flops = 2.0 * K * sim_r * sim_c * x3
         sim_ms = launches.get('sim_gemm', (0.0, 0))[0]
         if sim_ms > 0:
             hbm_frac = sim_bytes / (sim_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -388,7 +396,8 @@ def main():
                            'video %s (no FC: %s) + text %s (no FC: %s, bow sparse CSR)' % (spec['vid'], spec['vis_no_transform'],
                                                                                          spec['txt'], spec['txt_no_transform']),
                            heads, d),
-                       'parallelism': 'video-row shards x%d, all-gather of text operand' % world if world > 1 else 'single GPU',
+                       'parallelism': (('video-row shards x%d, all-gather of text operand' if args.shard == 'video' else
+                                        'text-row shards x%d, all-gather of video operand + ranks') % world) if world > 1 else 'single GPU',
                        'scores': 'fp32 S materialised in HBM',
                        'launch': launch_mode},
             'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6],

@@ -248,3 +248,87 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
                 metrics = compute.metrics(ranks)
         mark('metrics')
     return {'S_local': S_local, 'col0': v0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb}
+
+
+def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
+                             want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False,
+                             finish_tag=''):
+    """The OTHER decomposition the path admits (not the default: BASELINE.json asks for video-row shards with an all-gather of
+    the text operand): rank g owns texts [t0, t1) end to end and the ROW block S[t0:t1, :]; videos are split for the embedding
+    stage only and ONE all-gather of the 16-bit VIDEO operand (Nv x K: 10 MB at C4 instead of 41 MB for the texts) gives every
+    rank all videos.  Every text then meets its ground-truth video locally, so neither the MAX all-reduce of s_gt nor the SUM
+    all-reduce of the counts is needed; the ranks (Nt int32) are all-gathered for the replicated metrics.
+    Returns dict(S_local (t1-t0, Nv), row0, ranks (Nt,), metrics)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    comm = world > 1 or (force_collectives and dist.is_initialized())
+    t0, t1 = shard_bounds(Nt, world, rank)
+    run = runner if runner is not None else _eager
+    state = state if state is not None else {}
+    if runner is not None and metrics_out is None and want_metrics:
+        raise ValueError('a GraphRunner needs metrics_out (pinned buffer): the synchronising metrics call cannot be captured')
+    vsizes = [shard_bounds(Nv, world, r) for r in range(world)]
+    tsizes = [shard_bounds(Nt, world, r) for r in range(world)]
+    vmax = max(hi - lo for lo, hi in vsizes)
+    tmax = max(hi - lo for lo, hi in tsizes)
+    even = all(hi - lo == vmax for lo, hi in vsizes) and all(hi - lo == tmax for lo, hi in tsizes)
+    if runner is not None and comm and not even:
+        raise NotImplementedError('uneven shards need compaction copies that are not captured; use eager mode')
+    with torch.no_grad():
+        def towers():
+            if hasattr(compute, 'embed_both'):
+                vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local)
+            else:
+                txt_emb, vis_emb = compute.embed_text(txt_feats_local), compute.embed_video(vis_feats_local)
+            T_local = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
+            V_local = compute.pack(vis_emb, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack(vis_emb)
+            if V_local.precision not in ('fp16', 'bf16'):
+                raise NotImplementedError("sharded evaluation gathers a single-plane 16-bit operand; precision '%s' is "
+                                          'single-GPU only for now' % V_local.precision)
+            row_bytes = V_local.K * 2
+            send = V_local.buf[:V_local.N * row_bytes]
+            if V_local.N != vmax:
+                pad = torch.zeros(vmax * row_bytes, dtype=torch.uint8, device=send.device)
+                pad[:send.numel()] = send
+                send = pad
+            return txt_emb, vis_emb, T_local, V_local, send.contiguous()
+        txt_emb, vis_emb, T_local, V_local, send = run('towers_t', towers)
+        row_bytes = V_local.K * 2
+        if comm:
+            if 'gathered_v' not in state or state['gathered_v'].numel() != world * vmax * row_bytes:
+                state['gathered_v'] = torch.empty(world * vmax * row_bytes, dtype=torch.uint8, device=send.device)
+            gathered = state['gathered_v']
+            dist.all_gather_into_tensor(gathered, send, group=group)
+            if even:
+                V_all = compute.operand_from_gathered(gathered, Nv, V_local.K, V_local)
+            else:
+                parts = [gathered[r * vmax * row_bytes: r * vmax * row_bytes + (hi - lo) * row_bytes] for r, (lo, hi) in enumerate(vsizes)]
+                V_all = compute.operand_from_gathered(torch.cat(parts), Nv, V_local.K, V_local)
+        else:
+            V_all = V_local
+        gt_local = gt[t0:t1].contiguous()
+
+        def rank_phase():
+            s_gt = compute.row_dot_gt(T_local, V_all, gt_local, heads, 0)
+            S_local, count = compute.sim_ranked(T_local, V_all, heads, gt_local, s_gt, 0, want_scores)
+            mine = (count + 1).to(torch.int32)
+            if mine.numel() != tmax:
+                pad = torch.ones(tmax, dtype=torch.int32, device=mine.device)
+                pad[:mine.numel()] = mine
+                mine = pad
+            return S_local, mine.contiguous()
+        S_local, mine = run('rank_t', rank_phase)
+        if comm:
+            if 'gathered_r' not in state or state['gathered_r'].numel() != world * tmax:
+                state['gathered_r'] = torch.empty(world * tmax, dtype=torch.int32, device=mine.device)
+            all_ranks = state['gathered_r']
+            dist.all_gather_into_tensor(all_ranks, mine, group=group)
+            ranks = all_ranks if even else torch.cat([all_ranks[r * tmax: r * tmax + (hi - lo)] for r, (lo, hi) in enumerate(tsizes)])
+        else:
+            ranks = mine[:Nt]
+        metrics = None
+        if metrics_out is not None:
+            run('finish_t' + finish_tag, lambda: compute.metrics_async(ranks, metrics_out))
+        elif want_metrics:
+            metrics = compute.metrics(ranks)
+    return {'S_local': S_local, 'row0': t0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb}

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from laff_amd.dist import evaluate_sharded, shard_bounds
+from laff_amd.dist import evaluate_sharded, evaluate_sharded_by_text, shard_bounds
 from oracle import laff_oracle as O
 
 
@@ -30,7 +30,7 @@ class OracleBackend:
     def embed_video(self, f):
         return torch.from_numpy(O.l2norm(np.tanh(f['x'].numpy() @ self.Wv)))
 
-    def pack(self, E):
+    def pack(self, E, layer=None):
         h = E.to(torch.float16).contiguous()
         return Packed(h.view(torch.uint8).reshape(-1), E.shape[0], E.shape[1])
 
@@ -120,3 +120,38 @@ def test_sharded_equals_single(world, tmp_path):
         np.testing.assert_allclose(z['metrics'], np.array(single['metrics']), rtol=0, atol=1e-12)
         cols.append(z['S'])
     np.testing.assert_allclose(np.concatenate(cols, axis=1), single['S_local'].numpy(), rtol=0, atol=1e-6)
+
+
+def _worker_by_text(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        xt, xv, gt, Wt, Wv = _problem()
+        t0, t1 = shard_bounds(len(xt), world, rank)
+        v0, v1 = shard_bounds(len(xv), world, rank)
+        res = evaluate_sharded_by_text(OracleBackend(Wt, Wv), {'x': torch.from_numpy(xv[v0:v1])}, {'x': torch.from_numpy(xt[t0:t1])},
+                                       torch.from_numpy(gt), len(xt), len(xv), 1)
+        np.savez(os.path.join(out_dir, 't%d.npz' % rank), ranks=res['ranks'].numpy(), metrics=np.array(res['metrics']),
+                 S=res['S_local'].numpy(), row0=res['row0'])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_text_row_sharding_equals_single(world, tmp_path):
+    """The alternative decomposition (text-row blocks of S, all-gather of the VIDEO operand, all-gather of the ranks)."""
+    xt, xv, gt, Wt, Wv = _problem()
+    single = evaluate_sharded(OracleBackend(Wt, Wv), {'x': torch.from_numpy(xv)}, {'x': torch.from_numpy(xt)},
+                              torch.from_numpy(gt), len(xt), len(xv), 1)
+    alone = evaluate_sharded_by_text(OracleBackend(Wt, Wv), {'x': torch.from_numpy(xv)}, {'x': torch.from_numpy(xt)},
+                                     torch.from_numpy(gt), len(xt), len(xv), 1)
+    assert np.array_equal(alone['ranks'].numpy(), single['ranks'].numpy())
+    mp.spawn(_worker_by_text, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rows = []
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), 't%d.npz' % r))
+        assert np.array_equal(z['ranks'], single['ranks'].numpy())          # uneven shards (61 / 23 rows) included
+        np.testing.assert_allclose(z['metrics'], np.array(single['metrics']), rtol=0, atol=1e-12)
+        rows.append(z['S'])
+    np.testing.assert_allclose(np.concatenate(rows, axis=0), single['S_local'].numpy(), rtol=0, atol=1e-6)

@@ -306,3 +306,39 @@ def test_fused_input_split_is_bit_identical_to_the_materialised_split():
     out = ops.fc_act_bn_fused_grouped([dict(x=view, weight_split=Ws[0], bias=b, activation=None)])[0]
     ref = ops.fc_act_bn(view.contiguous(), W[0], b, None, None, None)
     assert float((out - ref).abs().max()) <= 2e-5
+
+
+def test_text_row_sharding_on_one_rank_rccl_group():
+    """The alternative decomposition (text-row blocks, all-gather of the video operand and of the ranks) on a 1-rank RCCL group,
+    eager and with per-phase graphs: same ranks, scores and metrics as the default path."""
+    import socket
+    import torch.distributed as dist
+    from laff_amd import synth
+    from laff_amd.dist import GraphRunner, HipBackend, evaluate_sharded, evaluate_sharded_by_text
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device(DEV)
+    Nt, Nv, H, d, _ = synth.WORKLOADS['c2_10kx3k']
+    model = synth.build_model(H, d, dev)
+    vis, txt, gt, _ = synth.make_features(Nt, Nv, dev)
+    backend = HipBackend(model, 'fp16')
+    ref = evaluate_sharded(backend, vis, txt, gt, Nt, Nv, H)
+    alone = evaluate_sharded_by_text(backend, vis, txt, gt, Nt, Nv, H)
+    assert torch.equal(alone['ranks'], ref['ranks']) and torch.equal(alone['S_local'], ref['S_local'])
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, world_size=1, rank=0, device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        eager = evaluate_sharded_by_text(backend, vis, txt, gt, Nt, Nv, H, force_collectives=True)
+        assert torch.equal(eager['ranks'], ref['ranks']) and torch.equal(eager['S_local'], ref['S_local'])
+        np.testing.assert_allclose(eager['metrics'], ref['metrics'], rtol=1e-13)
+        pinned = torch.zeros(8, dtype=torch.float64).pin_memory()
+        runner, state = GraphRunner(), {}
+        for _ in range(3):
+            out = evaluate_sharded_by_text(backend, vis, txt, gt, Nt, Nv, H, force_collectives=True, runner=runner, state=state,
+                                           metrics_out=pinned)
+            torch.cuda.synchronize()
+            assert torch.equal(out['ranks'], ref['ranks']) and torch.equal(out['S_local'], ref['S_local'])
+            np.testing.assert_allclose(pinned[:7].numpy(), ref['metrics'], rtol=1e-13)
+    finally:
+        dist.destroy_process_group()
