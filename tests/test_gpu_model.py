@@ -219,3 +219,28 @@ def test_text_feature_producers_on_device_match_reference_fixture(golden):
     ref = O.transform_net(z['bow_nsw'].astype(np.float32), sd['fc1.weight'], sd['fc1.bias'], 'tanh',
                           O._bn_from_sd(sd, ''))
     assert np.abs(y.cpu().numpy() - ref).max() <= 1e-5
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's keys plus roofline / cpu_baseline (tiny workload, child process)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'tiny', '--steps', '4', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in line, k
+    assert line['n_gpus'] == 1 and line['steps'] == 4 and line['warmup'] == 1 and line['higher_is_better'] is True
+    assert line['vs_baseline'] is None and line['data'] == 'synthetic' and 'workload' in line['config']
+    assert line['value'] > 0 and abs(line['value'] - 512 * 192 / (line['ms_per_step'] * 1e-3)) <= 1e-6 * line['value']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in line['roofline'], k
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in line['cpu_baseline'], k
