@@ -331,7 +331,9 @@ def main():
             'pack_rows': ('hbm', (4.0 + 2.0 * (2 if x3 == 3 else 1)) * (ntl + nvl) * K, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'rank_count': ('hbm', 4.0 * Nt * nvl, HBM_PEAK_GBS, 1e9, 'GB/s'),
             'gather_gt': ('hbm', 8.0 * Nt, HBM_PEAK_GBS, 1e9, 'GB/s'),
-            'row_dot_gt': ('hbm', 2.0 * 2 * Nt * K, HBM_PEAK_GBS, 1e9, 'GB/s'),
+            'row_dot_gt': ('hbm', 2.0 * K * (Nt + min(Nt, nvl)), HBM_PEAK_GBS, 1e9, 'GB/s'),
+            # embeddings (fp32) + operands (16-bit) of every row once, + the ground-truth video row of every text (at most nvl distinct)
+            'rank_prepare': ('hbm', (4.0 + 2.0 * (2 if x3 == 3 else 1)) * K * (Nt + nvl) + 4.0 * K * min(Nt, nvl), HBM_PEAK_GBS, 1e9, 'GB/s'),
         }
         sim_r, sim_c = (ntl, Nv) if (args.shard == 'text' and distributed) else (Nt, nvl)
         sim_bytes = 4.0 * sim_r * sim_c + 2.0 * (sim_r + sim_c) * K              # fp32 S written once + 16-bit operands read once
@@ -373,19 +375,35 @@ def main():
             pass
         m = res['metrics']
         agreement = None
-        if world == 1 and not args.no_cpu_baseline and not args.precision.endswith('x3') and args.precision != 'fp32':
-            # outside the timed region: the same embeddings through the strict (hi/lo split, ~1e-7) similarity
+        if world == 1 and not args.no_cpu_baseline:
+            # outside the timed region: (i) the same embeddings through the strict (hi/lo split, ~1e-7) similarity with its own exact-rank
+            # pass, (ii) ranks of float64 scores of the same embeddings computed with torch on the device, in row blocks
             from laff_amd import ops as _ops
-            Ts = _ops.pack_rows(res['txt_emb'], True, 1e-13, 'fp16x3')
-            Vs = _ops.pack_rows(res['vis_emb'], True, 1e-13, 'fp16x3')
-            sg = _ops.row_dot_gt(Ts, Vs, gt, heads)
-            cs = torch.zeros(Nt, dtype=torch.int32, device=dev)
-            Ss = _ops.sim_gemm(Ts, Vs, heads=heads, gt_col=gt, s_gt=sg, count=cs)
-            ms = _ops.rank_metrics(cs + 1)
-            agreement = {'max_abs_score_diff_vs_fp16x3': float((Ss - res['S_local']).abs().max()),
+            te, ve = res['txt_emb'], res['vis_emb']
+            Ts = _ops.pack_rows(te, True, 1e-13, 'fp16x3')
+            Vs = _ops.pack_rows(ve, True, 1e-13, 'fp16x3')
+            Ss, cs, _st = _ops.exact_ranks(te, ve, Ts, Vs, gt)
+            ms = _ops.rank_metrics(cs, base=1)
+            t3 = te.reshape(Nt, heads, -1).double()
+            v3 = ve.reshape(Nv, heads, -1).double()
+            v3 = v3 / (v3.pow(2).sum(2, keepdim=True).sqrt() + (1e-13 + 1e-14))
+            r64 = torch.empty(Nt, dtype=torch.int32, device=dev)
+            for a in range(0, Nt, 4096):
+                tb = t3[a:a + 4096]
+                tb = tb / (tb.pow(2).sum(2, keepdim=True).sqrt() + (1e-13 + 1e-14))
+                S64 = torch.einsum('thd,vhd->tv', tb, v3) / heads
+                g = gt[a:a + 4096].long()
+                sg = S64.gather(1, g[:, None])
+                ab = S64 > sg
+                ab[torch.arange(ab.shape[0], device=dev), g] = False
+                r64[a:a + 4096] = ab.sum(1).to(torch.int32) + 1
+            listed = res['rank_state'].listed_pairs() if res.get('rank_state') is not None else (None, None)
+            agreement = {'max_abs_score_diff_vs_fp16x3': float((Ss - res['S_local']).abs().max()) if res.get('S_local') is not None else None,
                          'identical_ranks_frac': float(((cs + 1) == res['ranks']).float().mean()),
-                         'strict_R@1/5/10/MedR': [ms[0], ms[1], ms[2], ms[3]]}
-            del Ss, Ts, Vs
+                         'identical_ranks_frac_vs_fp64_scores': float((r64 == res['ranks']).float().mean()),
+                         'strict_R@1/5/10/MedR': [ms[0], ms[1], ms[2], ms[3]],
+                         'pairs_inside_error_band': listed[0], 'pair_list_overflow': listed[1]}
+            del Ss, Ts, Vs, t3, v3
         line = {
             'metric': 'text-video cosine pairs/sec', 'value': pairs / elapsed * args.steps, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 9
+#define LAFF_ABI_VERSION 10
 
 enum {
     LAFF_OK = 0,
@@ -221,6 +221,35 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
 int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
                     const int* gt_col, int col0, float* s_gt, int* zero_count);
 
+/* ---- a12 made EXACT on a reduced-precision GEMM ------------------------------------------------------------------------------
+ * The reference ranks come from fp32 scores (predictor.py:232-244 on model/model.py:1003-1016).  A 16-bit MFMA pass keeps the
+ * scores inside the 1e-4 contract but not the ranks, so the fused count is done against a PROVEN error band and the few pairs
+ * inside the band are re-scored exactly.  exact(t, v) = (1/H) sum_h <t_h, v_h> / ((|t_h| + eps)(|v_h| + eps)), eps = 1e-13 + 1e-14
+ * (loss.py:8-13, 30-34), evaluated in fp64 on the fp32 embeddings; rank = 1 + #{v != gt : exact(t, v) > exact(t, gt)}.
+ *
+ *   laff_rank_prepare      Et [Nt, H, d], Ev [Nv, H, d]: the fp32 embeddings (rows 16-byte aligned, d % 4 == 0); T, V: the GEMM
+ *                          operands made from them (laff_pack_rows / laff_fuse_packed; `precision`, `prescale` as given there).
+ *                          Writes s_gt64[t] = exact(t, gt_col[t] - col0) (-inf when that column is outside [0, Nv): another
+ *                          shard owns it -- all-reduce MAX the doubles), band_t [Nt] and band_v [Nv] with
+ *                          |S_gemm(t, v) - exact(t, v)| <= band_t[t] + band_v[v]  (measured operand rounding error of both rows by
+ *                          Cauchy-Schwarz + the fp32 accumulation bound), clears zero_count [Nt] (nullable) and the pair-list header.
+ *   laff_sim_gemm_banded   laff_sim_gemm whose fused count is exact-decidable: count[t] += #{v != gt : S > s_gt + band}, pairs with
+ *                          |S - s_gt| <= band are appended to `pairs` (uint32: header {n, overflow, 0, 0} then {row, col} x pair_cap;
+ *                          col is shard-local); S (nullable) receives (float)s_gt64 at the ground-truth entry.
+ *   laff_rank_resolve      re-scores the listed pairs: count[row] += exact > s_gt64[row]; S (nullable) takes the fp32 value of the
+ *                          exact score (one ulp above (float)s_gt64 where rounding would hide a strict inequality) so that ranks
+ *                          recounted from S equal count + 1.  More than pair_cap pairs: pairs[1] = 1 and count[0] is poisoned
+ *                          (negative), which trips the rank < 1 flag of laff_rank_metrics*.
+ * After laff_rank_resolve (and an all-reduce SUM of count when videos are sharded) count + 1 are the exact ranks. */
+int laff_rank_prepare(laff_ctx* ctx, const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
+                      int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t, float* band_v,
+                      int* zero_count, unsigned* pairs);
+int laff_sim_gemm_banded(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision, float* S,
+                         int lds, const int* gt_col, int col0, const double* s_gt64, const float* band_t, const float* band_v,
+                         int* count, unsigned* pairs, unsigned pair_cap);
+int laff_rank_resolve(laff_ctx* ctx, const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64,
+                      int* count, float* S, int lds, unsigned* pairs, unsigned pair_cap);
+
 /* s_gt[t] = S[t, gt_col[t]-col0] if that column is in [0,Nv) else -inf  (shard-local ground-truth score) */
 int laff_gather_gt(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0,
                    float* s_gt);
@@ -244,8 +273,8 @@ int laff_topk_rows(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, int K
  * out7 (host) = r1, r5, r10, medr, meanr, mir, mAP.  Reduced on the device (one small kernel), 56 bytes copied back;
  * synchronises the stream. */
 int laff_rank_metrics(laff_ctx* ctx, const int* r, int Nq, int base, int* ranks_out, double out7[7]);
-/* Same, without synchronising: out8 is PINNED HOST memory (8 doubles: the 7 metrics + an error flag word, non-zero if a
- * rank < 1 was seen); valid once the stream has been synchronised.  Capturable in a HIP graph. */
+/* Same, without synchronising: out8 is PINNED HOST memory (8 doubles: the 7 metrics + an error flag, 1.0 if a rank < 1 was
+ * seen -- the 7 metrics are then NaN -- else 0.0); valid once the stream has been synchronised.  Capturable in a HIP graph. */
 int laff_rank_metrics_async(laff_ctx* ctx, const int* r, int Nq, int base, int* ranks_out, double* out8_pinned_host);
 
 #ifdef __cplusplus

@@ -15,7 +15,7 @@
 struct laff_ctx {
     int device;
     hipStream_t stream;
-    double* d_metrics = nullptr;   // 7 doubles + 1 int flag (device)
+    double* d_metrics = nullptr;   // 7 doubles + 1 flag (device): 0.0 / 1.0 (a rank < 1 was seen: metrics are NaN)
     double* h_metrics = nullptr;   // pinned host mirror
 };
 
@@ -497,20 +497,24 @@ int laff_pack_rows(laff_ctx* ctx, const float* E, int N, int H, int d, int lde, 
     return LAFF_OK;
 }
 
-int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
-                  float* S, int lds, const int* gt_col, int col0, const float* s_gt, int* count) {
+static int sim_gemm_impl(laff_ctx* ctx, const char* who, const void* T, const void* V, int Nt, int Nv, int K, float scale,
+                         int precision, float* S, int lds, const int* gt_col, int col0, const float* s_gt, int* count,
+                         const double* s_gt64, const float* band_t, const float* band_v, unsigned* pairs, unsigned pair_cap) {
     CHECK_CTX(ctx);
     if (Nt == 0 || Nv == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
-    if (!T || !V) return fail(LAFF_E_ARG, "laff_sim_gemm: null T/V");
-    if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "laff_sim_gemm: bad precision %d", precision);
+    if (!T || !V) return fail(LAFF_E_ARG, "%s: null T/V", who);
+    if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "%s: bad precision %d", who, precision);
     const int esz = precision == LAFF_PREC_FP32 ? 4 : 2;
     if (Nt < 0 || Nv < 0 || K < 1 || ((long)K * esz) % 4)
-        return fail(LAFF_E_SHAPE, "laff_sim_gemm: K must be positive (and even for 16-bit operands) (Nt=%d Nv=%d K=%d)", Nt, Nv, K);
-    if (!S && !gt_col) return fail(LAFF_E_ARG, "laff_sim_gemm: nothing to produce (S and gt_col both null)");
-    if (S && lds < Nv) return fail(LAFF_E_SHAPE, "laff_sim_gemm: lds=%d < Nv=%d", lds, Nv);
-    if (gt_col && (!s_gt || !count)) return fail(LAFF_E_ARG, "laff_sim_gemm: gt_col needs s_gt and count");
-    if (!aligned16(T) || !aligned16(V)) return fail(LAFF_E_ALIGN, "laff_sim_gemm: operands must be 16-byte aligned");
-    if (Nt == 0 || Nv == 0) return LAFF_OK;
+        return fail(LAFF_E_SHAPE, "%s: K must be positive (and even for 16-bit operands) (Nt=%d Nv=%d K=%d)", who, Nt, Nv, K);
+    if (!S && !gt_col) return fail(LAFF_E_ARG, "%s: nothing to produce (S and gt_col both null)", who);
+    if (S && lds < Nv) return fail(LAFF_E_SHAPE, "%s: lds=%d < Nv=%d", who, lds, Nv);
+    if (gt_col && !count) return fail(LAFF_E_ARG, "%s: gt_col needs count", who);
+    if (gt_col && !s_gt && !s_gt64) return fail(LAFF_E_ARG, "%s: gt_col needs the ground-truth scores", who);
+    if (s_gt64 && (!gt_col || !band_t || !band_v || !pairs || pair_cap < 1))
+        return fail(LAFF_E_ARG, "%s: the banded count needs gt_col, band_t, band_v and a pair list", who);
+    if (s_gt64 && !aligned16(band_v)) return fail(LAFF_E_ALIGN, "%s: band_v must be 16-byte aligned", who);
+    if (!aligned16(T) || !aligned16(V)) return fail(LAFF_E_ALIGN, "%s: operands must be 16-byte aligned", who);
     laff::GemmArgs a{};
     a.R = T; a.C = V; a.nR = Nt; a.nC = Nv; a.K = K; a.ldR = K; a.ldC = K;
     const long planeT = (long)Nt * K * 2, planeV = (long)Nv * K * 2;
@@ -525,6 +529,7 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
     }
     a.out = S; a.ldo = lds; a.scale = scale;
     a.gt_col = gt_col; a.col0 = col0; a.s_gt = s_gt; a.count = gt_col ? count : nullptr;
+    a.s_gt64 = s_gt64; a.band_r = band_t; a.band_c = band_v; a.pairs = pairs; a.pair_cap = pair_cap;
     if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
     int mode = laff::GEMM_F32;
     if (precision == LAFF_PREC_FP16 || precision == LAFF_PREC_FP16X3) mode = laff::GEMM_F16;
@@ -533,6 +538,52 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
     // rows of K elements: 16-byte aligned rows take the direct-to-LDS paths (K bytes a multiple of 128: the fast one),
     // anything else is staged through registers with element-wise K bounds
     HIP_TRY(laff::launch_gemm_nt(a, mode, ((long)K * esz) % 16 == 0, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
+                  float* S, int lds, const int* gt_col, int col0, const float* s_gt, int* count) {
+    if (gt_col && !s_gt) return fail(LAFF_E_ARG, "laff_sim_gemm: gt_col needs s_gt and count");
+    return sim_gemm_impl(ctx, "laff_sim_gemm", T, V, Nt, Nv, K, scale, precision, S, lds, gt_col, col0, s_gt, count, nullptr, nullptr,
+                         nullptr, nullptr, 0);
+}
+
+int laff_sim_gemm_banded(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision, float* S,
+                         int lds, const int* gt_col, int col0, const double* s_gt64, const float* band_t, const float* band_v,
+                         int* count, unsigned* pairs, unsigned pair_cap) {
+    if (!gt_col || !s_gt64) return fail(LAFF_E_ARG, "laff_sim_gemm_banded: null gt_col / s_gt64");
+    return sim_gemm_impl(ctx, "laff_sim_gemm_banded", T, V, Nt, Nv, K, scale, precision, S, lds, gt_col, col0, nullptr, count, s_gt64,
+                         band_t, band_v, pairs, pair_cap);
+}
+
+int laff_rank_prepare(laff_ctx* ctx, const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
+                      int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t, float* band_v,
+                      int* zero_count, unsigned* pairs) {
+    CHECK_CTX(ctx);
+    if (Nt == 0 && Nv == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
+    if ((Nt > 0 && (!Et || !T || !gt_col || !s_gt64 || !band_t)) || (Nv > 0 && (!Ev || !V || !band_v)))
+        return fail(LAFF_E_ARG, "laff_rank_prepare: null argument");
+    if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "laff_rank_prepare: bad precision %d", precision);
+    if (Nt < 0 || Nv < 0 || H < 1 || d < 4 || (d & 3)) return fail(LAFF_E_SHAPE, "laff_rank_prepare: need H >= 1, d %% 4 == 0 (Nt=%d Nv=%d H=%d d=%d)", Nt, Nv, H, d);
+    if (!(prescale > 0.0f)) return fail(LAFF_E_ARG, "laff_rank_prepare: prescale must be positive");
+    if ((Et && !aligned16(Et)) || (Ev && !aligned16(Ev)) || (T && !aligned16(T)) || (V && !aligned16(V)))
+        return fail(LAFF_E_ALIGN, "laff_rank_prepare: embeddings and operands must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_rank_prepare(Et, Ev, T, V, Nt, Nv, H, d, precision, prescale, gt_col, col0, s_gt64, band_t, band_v, zero_count,
+                                      pairs, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_rank_resolve(laff_ctx* ctx, const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64,
+                      int* count, float* S, int lds, unsigned* pairs, unsigned pair_cap) {
+    CHECK_CTX(ctx);
+    if (Nt == 0 || Nv == 0) return LAFF_OK;                 /* empty problem: nothing was listed */
+    if (!Et || !Ev || !s_gt64 || !count || !pairs) return fail(LAFF_E_ARG, "laff_rank_resolve: null argument");
+    if (Nt < 0 || Nv < 0 || H < 1 || d < 4 || (d & 3) || pair_cap < 1) return fail(LAFF_E_SHAPE, "laff_rank_resolve: bad shape");
+    if (S && lds < Nv) return fail(LAFF_E_SHAPE, "laff_rank_resolve: lds=%d < Nv=%d", lds, Nv);
+    if (!aligned16(Et) || !aligned16(Ev)) return fail(LAFF_E_ALIGN, "laff_rank_resolve: embeddings must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_rank_resolve(Et, Ev, Nt, Nv, H, d, s_gt64, count, S, lds, pairs, pair_cap, ctx->stream));
     return LAFF_OK;
 }
 
@@ -605,9 +656,10 @@ int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, int base, i
     DeviceGuard g(ctx->device);
     if (!ctx->d_metrics) {
         HIP_TRY(hipMalloc((void**)&ctx->d_metrics, 8 * sizeof(double)));
+        HIP_TRY(hipMemset(ctx->d_metrics, 0, 8 * sizeof(double)));
         HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
     }
-    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, (int*)(ctx->d_metrics + 7), ctx->stream));
+    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, ctx->d_metrics + 7, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out8, ctx->d_metrics, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return LAFF_OK;
 }
@@ -619,12 +671,15 @@ int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, int base, int* ra
     DeviceGuard g(ctx->device);
     if (!ctx->d_metrics) {
         HIP_TRY(hipMalloc((void**)&ctx->d_metrics, 8 * sizeof(double)));
+        HIP_TRY(hipMemset(ctx->d_metrics, 0, 8 * sizeof(double)));
         HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
     }
-    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, (int*)(ctx->d_metrics + 7), ctx->stream));
+    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, ctx->d_metrics + 7, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_metrics, ctx->d_metrics, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (*(const int*)(ctx->h_metrics + 7)) return fail(LAFF_E_ARG, "laff_rank_metrics: ranks must be 1-based (found a value < 1)");
+    if (ctx->h_metrics[7] != 0.0)
+        return fail(LAFF_E_ARG, "laff_rank_metrics: a rank < 1 was found (ranks must be 1-based; a poisoned count also means the pair "
+                                "list of laff_sim_gemm_banded overflowed)");
     for (int i = 0; i < 7; ++i) out7[i] = ctx->h_metrics[i];
     return LAFF_OK;
 }

@@ -168,7 +168,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
     const int l31 = lane & 31, hh = lane >> 5;
     float* slab = (float*)smem + wave * (32 * PITCH);
     const int cw0 = c0 + wc * (WN * 32);               // first output column of this wave
-    const bool counting = EPI == EPI_SIM && a.count != nullptr;
+    const bool banded = EPI == EPI_SIM && a.count != nullptr && a.s_gt64 != nullptr;
+    const bool counting = EPI == EPI_SIM && a.count != nullptr && !banded;
 #pragma unroll
     for (int tr = 0; tr < WM; ++tr) {
         const int rbase = r0 + wr * (WM * 32) + tr * 32;
@@ -176,10 +177,15 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
         const bool row_ok = FULL || rr < a.nR;
         int cnt = 0;
         int gt = -1;
-        float sg = 0.0f;
+        float sg = 0.0f, eband = 0.0f;
         if (counting && row_ok) {
             gt = a.gt_col[rr] - a.col0;
             sg = a.s_gt[rr];
+        }
+        if (banded && row_ok) {
+            gt = a.gt_col[rr] - a.col0;
+            sg = (float)a.s_gt64[rr];
+            eband = a.band_r[rr];
         }
         float rscl = a.scale;
         if (EPI == EPI_FC && a.row_scale && row_ok) rscl *= a.row_scale[rr];
@@ -235,10 +241,49 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
                         cnt += (in && v[e] > sg) ? 1 : 0;
                     }
                 }
+                if (banded) {
+                    // Exact-rank count (laff_rank_prepare / laff_rank_resolve): a score further than the proven error band from
+                    // the exact ground-truth score is decided here; a pair inside the band is appended to the list that
+                    // laff_rank_resolve re-scores exactly (fp64 on the fp32 embeddings).  The ground-truth pair is inside its own
+                    // band by construction: it is recognised by index, takes the exact value in S and is never listed.
+                    float bc[4] = {0, 0, 0, 0};
+                    if (FULL || cc + 3 < a.nC) {
+                        *(float4*)bc = *(const float4*)(a.band_c + cc);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (cc + e < a.nC) bc[e] = a.band_c[cc + e];
+                    }
+                    bool any = (unsigned)(gt - cc) < 4u;                     // the ground-truth column is in this quad
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dlt = v[e] - sg, eps = eband + bc[e];
+                        const bool in = FULL || (row_ok && cc + e < a.nC);
+                        cnt += (in && dlt > eps) ? 1 : 0;
+                        any |= in && __builtin_fabsf(dlt) <= eps;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(any) != 0ull) {          // rare: ~1e-4 of the pairs + one quad per row
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float dlt = v[e] - sg, eps = eband + bc[e];
+                            const bool in = FULL || (row_ok && cc + e < a.nC);
+                            if (in && cc + e == gt) {
+                                cnt -= (dlt > eps) ? 1 : 0;                  // never counted, whatever its approximate value
+                                v[e] = sg;
+                            } else if (in && __builtin_fabsf(dlt) <= eps) {
+                                const unsigned slot = atomicAdd(a.pairs, 1u);
+                                if (slot < a.pair_cap) {
+                                    a.pairs[4 + 2 * (size_t)slot] = (unsigned)rr;
+                                    a.pairs[5 + 2 * (size_t)slot] = (unsigned)(cc + e);
+                                }
+                            }
+                        }
+                    }
+                }
                 if (a.out) *(float4*)(slab + l31 * PITCH + cl) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
-        if (counting) {
+        if (counting || banded) {
             cnt += __shfl_xor(cnt, 32);
             if (hh == 0 && row_ok && cnt) atomicAdd(a.count + rr, cnt);
         }

@@ -33,6 +33,12 @@ struct GemmArgs {
     int col0;
     const float* s_gt;
     int* count;
+    // exact-rank ("banded") count: definite counts here, pairs inside the error band go to a list for laff_rank_resolve
+    const double* s_gt64;     // [nR] exact ground-truth scores (laff_rank_prepare); non-null selects the banded epilogue
+    const float* band_r;      // [nR] row part of the band half-width
+    const float* band_c;      // [nC] column part
+    unsigned* pairs;          // header {count, overflow, 0, 0} + pair_cap x {row, col}
+    unsigned pair_cap;
     unsigned long long* trace;   // debug (LAFF_GEMM_TRACE build only): 8 timestamps per workgroup
 };
 
@@ -115,7 +121,12 @@ hipError_t launch_pack_rows(const float* E, int N, int H, int d, int lde, int no
 
 hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K, int bf16, int x3, float scale,
                              const int* gt_col, int col0, float* s_gt, int* zero_count, hipStream_t st);
-hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, int* err, hipStream_t st);
+hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
+                               int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t,
+                               float* band_v, int* zero_count, unsigned* pairs, hipStream_t st);
+hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64, int* count,
+                               float* S, int lds, unsigned* pairs, unsigned pair_cap, hipStream_t st);
+hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, hipStream_t st);
 hipError_t launch_gather_gt(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt,
                             hipStream_t st);
 hipError_t launch_rank_count(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, const float* s_gt,

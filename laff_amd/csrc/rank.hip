@@ -157,8 +157,196 @@ hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K
     return hipGetLastError();
 }
 
+// ---- exact ranks on a reduced-precision similarity GEMM ----------------------------------------------------------------
+// The reference ranks on fp32 cosine scores (predictor.py:232-244 on model/model.py:1003-1016); a 16-bit MFMA pass is inside
+// the 1e-4 score contract but moves ~3 % of the ranks by one place.  Ranks are index work, so they are made exact:
+//   exact(t, v) = (1/H) sum_h <t_h, v_h> / ((|t_h| + eps)(|v_h| + eps))     in fp64 on the fp32 embeddings
+// (the infinitely precise value of what loss.cosine_sim computes in fp32; products of fp32 values are exact in fp64).
+//   * laff_rank_prepare : s_gt64[t] = exact(t, gt(t)); for every operand row the MEASURED quantisation error
+//                         q = |operand/prescale - normalised embedding|_2, turned into band halves
+//                             band_t[t] = q_t / sqrt(H) * (1 + u) + K * 2^-23 + 2^-22,   band_v[v] = q_v / sqrt(H)
+//                         so that |approx(t,v) - exact(t,v)| <= band_t[t] + band_v[v]   (Cauchy-Schwarz on
+//                         dt.v + t.dv + dt.dv with |t^| = |v^| = sqrt(H); u = unit roundoff of the operand format bounds the
+//                         cross term; K * 2^-23 covers the fp32 accumulation of K exact products under round-to-nearest or
+//                         truncation, 2^-22 the final scaling and the fp32 copy of s_gt64);
+//   * the GEMM epilogue decides every pair outside the band and lists the pairs inside it (gemm_nt.hip);
+//   * laff_rank_resolve  re-scores the listed pairs with exact() and fixes count / S.
+// One wavefront per row / pair; lanes own float4 columns {256 j + 4 lane}.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+constexpr double COS_EPS = 1e-13 + 1e-14;      // loss.cosine_sim -> l2norm(eps=1e-13): X / (norm + eps + 1e-14)  (loss.py:8-13,30-34)
+
+// every lane returns the same value; identical arithmetic wherever it is called, so equal rows give equal scores
+__device__ __forceinline__ double exact_cos(const float* __restrict__ t, const float* __restrict__ v, int H, int d, int lane) {
+    double s = 0.0;
+    for (int h = 0; h < H; ++h) {
+        const float* th = t + (long)h * d;
+        const float* vh = v + (long)h * d;
+        double tt = 0.0, vv = 0.0, tv = 0.0;
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 a = *(const float4*)(th + c), b = *(const float4*)(vh + c);
+            const double ax = a.x, ay = a.y, az = a.z, aw = a.w, bx = b.x, by = b.y, bz = b.z, bw = b.w;
+            tt = fma(ax, ax, tt); tt = fma(ay, ay, tt); tt = fma(az, az, tt); tt = fma(aw, aw, tt);
+            vv = fma(bx, bx, vv); vv = fma(by, by, vv); vv = fma(bz, bz, vv); vv = fma(bw, bw, vv);
+            tv = fma(ax, bx, tv); tv = fma(ay, by, tv); tv = fma(az, bz, tv); tv = fma(aw, bw, tv);
+        }
+        tt = wave_sum_f64(tt); vv = wave_sum_f64(vv); tv = wave_sum_f64(tv);
+        s += tv / ((sqrt(tt) + COS_EPS) * (sqrt(vv) + COS_EPS));
+    }
+    return s / (double)H;
+}
+
+// q^2 = sum_k (operand[k] / prescale - e[k] / (|e_h| + eps))^2 over the whole row; PREC as LAFF_PREC_*
+template <int PREC>
+__device__ __forceinline__ float quant_err2(const float* __restrict__ e, const void* __restrict__ op, long row, long nrows, int H,
+                                            int d, float inv_prescale, int lane) {
+    const long K = (long)H * d;
+    float q2 = 0.f;
+    for (int h = 0; h < H; ++h) {
+        const float* eh = e + (long)h * d;
+        double nn = 0.0;
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 a = *(const float4*)(eh + c);
+            nn = fma((double)a.x, (double)a.x, nn); nn = fma((double)a.y, (double)a.y, nn);
+            nn = fma((double)a.z, (double)a.z, nn); nn = fma((double)a.w, (double)a.w, nn);
+        }
+        const double inv = 1.0 / (sqrt(wave_sum_f64(nn)) + COS_EPS);
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 a = *(const float4*)(eh + c);
+            const float ref[4] = {(float)(a.x * inv), (float)(a.y * inv), (float)(a.z * inv), (float)(a.w * inv)};
+            float x[4];
+            const long k = row * K + (long)h * d + c;
+            if constexpr (PREC == LAFF_PREC_FP32) {
+                const float4 o = *(const float4*)((const float*)op + k);
+                x[0] = o.x; x[1] = o.y; x[2] = o.z; x[3] = o.w;
+            } else {
+                auto cvt = [](uint16_t b) -> float {
+                    if constexpr (PREC == LAFF_PREC_BF16 || PREC == LAFF_PREC_BF16X3) return __uint_as_float((unsigned)b << 16);
+                    else { _Float16 f; __builtin_memcpy(&f, &b, 2); return (float)f; }
+                };
+                const uint2 o = *(const uint2*)((const uint16_t*)op + k);
+                x[0] = cvt((uint16_t)o.x); x[1] = cvt((uint16_t)(o.x >> 16)); x[2] = cvt((uint16_t)o.y); x[3] = cvt((uint16_t)(o.y >> 16));
+                if constexpr (PREC == LAFF_PREC_FP16X3 || PREC == LAFF_PREC_BF16X3) {
+                    const uint2 l = *(const uint2*)((const uint16_t*)op + nrows * K + k);
+                    x[0] += cvt((uint16_t)l.x); x[1] += cvt((uint16_t)(l.x >> 16)); x[2] += cvt((uint16_t)l.y); x[3] += cvt((uint16_t)(l.y >> 16));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dl = fmaf(x[i], inv_prescale, -ref[i]);
+                q2 = fmaf(dl, dl, q2);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q2 += __shfl_xor(q2, o);
+    return q2;
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restrict__ Et, const float* __restrict__ Ev,
+                                                           const void* __restrict__ T, const void* __restrict__ V, int Nt, int Nv,
+                                                           int H, int d, float inv_prescale, float unit, float c_acc, const int* __restrict__ gt_col,
+                                                           int col0, double* __restrict__ s_gt64, float* __restrict__ band_t,
+                                                           float* __restrict__ band_v, int* __restrict__ zero_count,
+                                                           unsigned* __restrict__ pairs) {
+    const int lane = threadIdx.x & 63;
+    const long K = (long)H * d;
+    const long tblocks = ((long)Nt + 3) / 4;
+    if (blockIdx.x == 0 && threadIdx.x < 4 && pairs) pairs[threadIdx.x] = 0u;       // pair counter + overflow flag
+    const float rsqrt_h = 1.0f / sqrtf((float)H);
+    if ((long)blockIdx.x < tblocks) {
+        const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (t >= Nt) return;
+        if (zero_count && lane == 0) zero_count[t] = 0;
+        const float* e = Et + t * K;
+        const float q = sqrtf(quant_err2<PREC>(e, T, t, Nt, H, d, inv_prescale, lane));
+        const int c = gt_col[t] - col0;
+        double sg = -INFINITY;
+        if (c >= 0 && c < Nv) sg = exact_cos(e, Ev + (long)c * K, H, d, lane);
+        if (lane == 0) {
+            s_gt64[t] = sg;
+            band_t[t] = q * rsqrt_h * (1.0f + unit) * 1.0001f + c_acc;
+        }
+    } else {
+        const long v = ((long)blockIdx.x - tblocks) * 4 + (threadIdx.x >> 6);
+        if (v >= Nv) return;
+        const float q = sqrtf(quant_err2<PREC>(Ev + v * K, V, v, Nv, H, d, inv_prescale, lane));
+        if (lane == 0) band_v[v] = q * rsqrt_h * 1.0001f;
+    }
+}
+
+hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
+                               int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t,
+                               float* band_v, int* zero_count, unsigned* pairs, hipStream_t st) {
+    const long grid = ((long)Nt + 3) / 4 + ((long)Nv + 3) / 4;
+    if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
+    const float inv = 1.0f / prescale;
+    // fp32 accumulation of the exact products: K terms (3K for a hi/lo split, plus its dropped lo*lo term <= 2^-22), 2^-23 each
+    // (covers round-to-nearest and truncating accumulators), + 2^-22 for the final scaling and the fp32 copy of s_gt64
+    const bool x3 = precision == LAFF_PREC_FP16X3 || precision == LAFF_PREC_BF16X3;
+    const float c_acc = (float)((double)H * d * (x3 ? 3.0 : 1.0) * 1.1920929e-7 + 2.3841858e-7 * (x3 ? 2.0 : 1.0));
+#define LAFF_PREP(P, U)                                                                                                          \
+    hipLaunchKernelGGL((rank_prepare_kernel<P>), dim3((unsigned)grid), dim3(256), 0, st, Et, Ev, T, V, Nt, Nv, H, d, inv, U, c_acc, gt_col, \
+                       col0, s_gt64, band_t, band_v, zero_count, pairs)
+    switch (precision) {
+        case LAFF_PREC_FP32: LAFF_PREP(LAFF_PREC_FP32, 5.9604645e-8f); break;
+        case LAFF_PREC_FP16: LAFF_PREP(LAFF_PREC_FP16, 4.8828125e-4f); break;
+        case LAFF_PREC_BF16: LAFF_PREP(LAFF_PREC_BF16, 3.90625e-3f); break;
+        case LAFF_PREC_FP16X3: LAFF_PREP(LAFF_PREC_FP16X3, 4.8828125e-4f); break;
+        case LAFF_PREC_BF16X3: LAFF_PREP(LAFF_PREC_BF16X3, 3.90625e-3f); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef LAFF_PREP
+    return hipGetLastError();
+}
+
+// one wavefront per listed pair, grid-stride.  count[row] += 1 when the exact score beats the exact ground-truth score; S (optional)
+// takes the fp32 value of the exact score, nudged by one ulp where rounding to fp32 would hide a strict inequality, so that ranks
+// recounted from S (laff_rank_count) equal the ranks produced here.  More pairs than the list holds: overflow flag + count[0]
+// poisoned (rank < 1 trips the error flag of laff_rank_metrics*).
+__global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d,
+                                                           const double* __restrict__ s_gt64, int* __restrict__ count,
+                                                           float* __restrict__ S, long lds, unsigned* __restrict__ pairs,
+                                                           unsigned pair_cap) {
+    const int lane = threadIdx.x & 63;
+    const unsigned total = pairs[0];
+    const long K = (long)H * d;
+    if (total > pair_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[1] = 1u; count[0] = -0x40000000; }
+    }
+    const unsigned n = total < pair_cap ? total : pair_cap;
+    const unsigned stride = gridDim.x * 4u;
+    for (unsigned i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += stride) {
+        const unsigned r = pairs[4 + 2 * (size_t)i], c = pairs[5 + 2 * (size_t)i];
+        const double ex = exact_cos(Et + (long)r * K, Ev + (long)c * K, H, d, lane);
+        const double sg = s_gt64[r];
+        const bool above = ex > sg;
+        if (lane == 0) {
+            if (above) atomicAdd(count + r, 1);
+            if (S) {
+                float f = (float)ex;
+                const float sgf = (float)sg;
+                if (above && !(f > sgf)) f = nextafterf(sgf, INFINITY);
+                S[(long)r * lds + c] = f;
+            }
+        }
+    }
+}
+
+hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64, int* count,
+                               float* S, int lds, unsigned* pairs, unsigned pair_cap, hipStream_t st) {
+    (void)Nt; (void)Nv;
+    hipLaunchKernelGGL(rank_resolve_kernel, dim3(2048), dim3(256), 0, st, Et, Ev, H, d, s_gt64, count, S, (long)lds, pairs, pair_cap);
+    return hipGetLastError();
+}
+
 // evaluation.eval (/root/reference/evaluation.py:92-109) for single-GT rows, on the device: one 1024-thread block.
-// out7 = r1, r5, r10, medr, meanr, mir, mAP (= mir).  err[0] != 0 if a rank < 1 was seen.
+// out7 = r1, r5, r10, medr, meanr, mir, mAP (= mir).  err[0] = 1.0 (and NaN metrics) if a rank < 1 was seen, else 0.0.
 // The median is an order statistic of positive integers: MSB-first radix select with 8-bit digits, starting at the top
 // non-zero byte of the largest rank (two passes for ranks < 65536).  The digit histogram lives in LDS with every bin
 // REPLICATED 32 times (replica = lane & 31, row pitch 33 words): retrieval ranks pile up on a few values (41 % are rank 1
@@ -167,7 +355,7 @@ hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K
 // One workgroup, ranks streamed from L2 each pass; all reductions of a phase share one barrier pair.
 // rank = r[i] + base (base = 1 turns the fused "better-scoring videos" counts into ranks); ranks_out, when given, receives them.
 __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, int base, int* __restrict__ ranks_out,
-                                                            double* __restrict__ out7, int* __restrict__ err) {
+                                                            double* __restrict__ out7, double* __restrict__ err) {
     __shared__ double shd[16];
     __shared__ unsigned long long shl[16][4];
     __shared__ int shm[16][2];
@@ -209,8 +397,9 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     for (int w = 0; w < 16; ++w) { mx = max(mx, shm[w][0]); mn = min(mn, shm[w][1]); }
     mx = __builtin_amdgcn_readfirstlane(mx);
     mn = __builtin_amdgcn_readfirstlane(mn);
-    if (n > 0 && mn < 1) {                                        // invalid input: report, do not select
-        if (tid == 0) err[0] = 1;
+    if (n > 0 && mn < 1) {                                        // invalid input: report (flag + NaN metrics), do not select
+        if (tid < 7) out7[tid] = __builtin_nan("");
+        if (tid == 0) err[0] = 1.0;
         return;
     }
     // ---- k-th smallest (0-based k = n/2)
@@ -277,11 +466,11 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
         const double dn = (double)n;
         out7[0] = 100.0 * ((double)c1 / dn); out7[1] = 100.0 * ((double)c5 / dn); out7[2] = 100.0 * ((double)c10 / dn);
         out7[3] = floor(med); out7[4] = (double)sum / dn; out7[5] = isum / dn; out7[6] = isum / dn;
-        err[0] = 0;
+        err[0] = 0.0;
     }
 }
 
-hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, int* err, hipStream_t st) {
+hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, hipStream_t st) {
     hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(1024), 0, st, r, n, base, ranks_out, out7, err);
     return hipGetLastError();
 }

@@ -1,14 +1,22 @@
 """Multi-GPU decomposition of the hot path (one process per GPU, torch.distributed; backend 'nccl' is RCCL over xGMI).
 
-The reference has no parallelism of any kind; this is the one data-parallel decomposition the
-path admits:
+The reference has no parallelism of any kind; the path shards by rows and admits two
+decompositions, both implemented:
 
-  * video rows are split contiguously: rank g owns videos [v0, v1) end to end (features -> embeddings -> its
-    column block S[:, v0:v1] of the score matrix);
-  * text rows are split the same way for the embedding stage only, then ONE all-gather of the text GEMM operand
-    (Nt x K 16-bit) gives every rank all texts; it is issued asynchronously and overlaps the video tower;
-  * ranks: s_gt[t] comes from the rank that owns gt(t) -> all-reduce(MAX) of Nt floats; every rank counts the
-    better-scoring videos of its block -> all-reduce(SUM) of Nt int32.  No other collective; S is never gathered.
+  'video' (evaluate_sharded; the scheme BASELINE.json names): rank g owns videos [v0, v1) end to end (features -> embeddings ->
+      its column block S[:, v0:v1]); text rows are split the same way for the embedding stage only, then ONE all-gather of the
+      fp32 TEXT embeddings (Nt x K) gives every rank all texts -- issued asynchronously, it overlaps the video tower; every rank
+      packs the gathered rows into the GEMM operand itself.  Ranks: the exact ground-truth score s_gt64[t] comes from the rank
+      that owns gt(t) -> all-reduce(MAX) of Nt doubles; every rank counts the better-scoring videos of its block (error-band
+      count + exact re-score, ops.rank_prepare / sim_gemm_banded / rank_resolve) -> all-reduce(SUM) of Nt int32.
+  'text' (evaluate_sharded_by_text): rank g owns texts [t0, t1) end to end and the ROW block S[t0:t1, :]; ONE all-gather of the fp32
+      VIDEO embeddings (Nv x K); every text meets its ground-truth video locally, so both all-reduces disappear; the ranks (Nt
+      int32) are all-gathered for the replicated metrics.
+
+The fp32 embeddings are what is gathered (not the 16-bit operand) because the exact re-score of the pairs inside the error band
+needs both fp32 rows of a pair on the rank that owns the pair.  choose_sharding() picks the scheme that gathers fewer bytes
+(min(Nt, Nv) x K).  S is never gathered.  Uneven shards are padded to the largest shard for the collective and compacted inside
+the next captured phase.
 
 `compute` is the per-rank kernel backend (HipBackend below; the gloo/CPU tests inject an oracle-backed stand-in),
 so the orchestration is exercised without a GPU.
@@ -73,11 +81,18 @@ class HipBackend:
         return [getattr(net, name) for net in (self.model.vis_net, self.model.txt_net)
                 for name in ('attention_layer', 'vis_attention_layer') if hasattr(net, name)]
 
+    def set_unpacked(self, side):
+        """side 'txt' | 'vis' | None: that tower's fuse launch does not emit the 16-bit operand (its embeddings are gathered in fp32
+        and packed after the collective)."""
+        self._unpacked = side
+
     def _emit_packed(self, on):
         fused = self.precision in ('fp16', 'bf16')
+        skip = {'txt': [self.txt_layer()], 'vis': [self.vis_layer()]}.get(getattr(self, '_unpacked', None), [])
         for layer in self._attention_layers():
             layer.emit_packed = self.precision if (on and fused and hasattr(layer, 'fuse_planes') and
-                                                   type(layer).__name__ != 'JustAverage') else None
+                                                   type(layer).__name__ != 'JustAverage' and
+                                                   not any(layer is x for x in skip)) else None
 
     def pack(self, E, layer=None):
         """GEMM operand of an embedding matrix: taken from the fuse launch when it emitted one, else a pack_rows pass."""
@@ -87,29 +102,29 @@ class HipBackend:
             return p
         return ops.pack_rows(E, True, 1e-13, self.precision)
 
-    def operand_from_gathered(self, bufs, rows, K, like):
-        """Concatenated single-plane operand buffers of all ranks -> one Packed operand."""
-        return ops.Packed(bufs, rows, K, like.precision, like.prescale)
+    def pack_gathered(self, E):
+        """GEMM operand of gathered fp32 embedding rows (N, H, d)."""
+        return ops.pack_rows(E, True, 1e-13, self.precision)
 
     def sim(self, T, V, heads):
         return ops.sim_gemm(T, V, heads=heads)
 
-    def row_dot_gt(self, T, V, gt, heads, col0):
-        # the same launch clears the accumulator the fused count of sim_ranked adds into (no separate fill kernel)
-        self._count = torch.empty((T.N,), dtype=torch.int32, device=T.buf.device)
-        return ops.row_dot_gt(T, V, gt, heads, col0, zero_count=self._count)
+    def prepare(self, Et, Ev, T, V, gt, col0):
+        """Exact ground-truth scores of the texts whose video is in [col0, col0 + Nv), error bands, cleared accumulators."""
+        return ops.rank_prepare(Et, Ev, T, V, gt, col0)
 
-    def sim_ranked(self, T, V, heads, gt, s_gt, col0, want_scores=True):
-        """Score block + ground-truth rank counts in one GEMM launch (fused epilogue)."""
-        count = getattr(self, '_count', None)
-        if count is None or count.numel() != T.N:
-            count = torch.zeros((T.N,), dtype=torch.int32, device=T.buf.device)
-        self._count = None
-        S = ops.sim_gemm(T, V, heads=heads, want_scores=want_scores, gt_col=gt, s_gt=s_gt, count=count, col0=col0)
-        return S, count
+    def s_gt_of(self, st):
+        return st.s_gt64
+
+    def sim_ranked(self, st, want_scores=True):
+        """Score block + exact ground-truth rank counts: banded GEMM epilogue, then the exact re-score of the listed pairs."""
+        S = ops.sim_gemm_banded(st, want_scores)
+        ops.rank_resolve(st, S)
+        return S, st.count
 
     def finish(self, count, out_pinned=None):
-        """ranks = count + 1 and the 7 metrics in one launch; returns (ranks, metrics or None when out_pinned is given)."""
+        """ranks = count + 1 and the 7 metrics in one launch; returns (ranks, metrics or None when out_pinned is given).
+        With out_pinned the caller checks out_pinned[7] (error flag) after its stream sync: check_metrics_flag()."""
         ranks = torch.empty_like(count)
         if out_pinned is not None:
             ops.rank_metrics_async(count, out_pinned, base=1, ranks_out=ranks)
@@ -145,10 +160,47 @@ def _eager(name, fn):
     return fn()
 
 
+def check_metrics_flag(out_pinned):
+    """After the stream sync that makes an async metrics buffer valid: raise if the device flagged the step (a rank < 1, which is
+    also how an overflowing pair list of the exact-rank pipeline reports itself)."""
+    if float(out_pinned[7]) != 0.0:
+        raise RuntimeError('laff_amd: the rank metrics kernel flagged an invalid rank (rank < 1): the pair list of the exact-rank '
+                           'pipeline overflowed (degenerate scores: raise pair_cap) or the counts are corrupt')
+
+
+def choose_sharding(Nt, Nv):
+    """The decomposition that gathers fewer embedding rows: 'text' shards (gather the videos) when Nv <= Nt, else 'video'."""
+    return 'text' if Nv <= Nt else 'video'
+
+
+def _flat_rows(E):
+    return E.reshape(E.shape[0], -1)
+
+
+def _pad_rows(E2, nmax):
+    """(n, K) -> contiguous (nmax, K), zero rows appended (equal-sized contributions for all_gather_into_tensor)."""
+    if E2.shape[0] == nmax:
+        return E2.contiguous()
+    pad = torch.zeros((nmax, E2.shape[1]), dtype=E2.dtype, device=E2.device)
+    pad[:E2.shape[0]] = E2
+    return pad
+
+
+def _compact(gathered, sizes, nmax, heads):
+    """Padded all-gather result (world * nmax, K) -> (N, heads, K / heads): drops the padding rows of uneven shards."""
+    K = gathered.shape[1]
+    if all(hi - lo == nmax for lo, hi in sizes):
+        rows = gathered
+    else:
+        rows = torch.cat([gathered[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
+    return rows.view(rows.shape[0], heads, K // heads)
+
+
 def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
                      timer=None, want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False,
                      finish_tag=''):
-    """One pass of the hot path on this rank's shards.  gt: (Nt,) int32 GLOBAL video column of every text (replicated).
+    """One pass of the hot path on this rank's shards, videos sharded ('video' scheme of the module docstring).
+    gt: (Nt,) int32 GLOBAL video column of every text (replicated).
 
     runner: None (eager) or a GraphRunner; state: dict that persists across steps (static collective buffers) -- required
     with a GraphRunner.  force_collectives runs the collectives even on a 1-rank group (used to exercise the N > 1 code
@@ -166,34 +218,27 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
         raise ValueError('a GraphRunner needs metrics_out (pinned buffer): the synchronising metrics call cannot be captured')
     sizes = [shard_bounds(Nt, world, r) for r in range(world)]
     nmax = max(hi - lo for lo, hi in sizes)
+    if hasattr(compute, 'set_unpacked'):
+        compute.set_unpacked('txt' if comm else None)
     with torch.no_grad():
         if not comm and hasattr(compute, 'embed_both'):
             def towers():
                 vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local)
                 return (txt_emb, compute.pack(txt_emb, compute.txt_layer()), vis_emb, compute.pack(vis_emb, compute.vis_layer()))
             txt_emb, T_all, vis_emb, V_local = run('towers', towers)
+            Et_all = txt_emb
             mark('towers')
         else:
             def text_phase():
                 txt_emb = compute.embed_text(txt_feats_local)
-                T_local = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
-                if T_local.precision not in ('fp16', 'bf16'):
-                    raise NotImplementedError("sharded evaluation gathers a single-plane 16-bit operand; precision '%s' "
-                                              "is single-GPU only for now" % T_local.precision)
-                row_bytes = T_local.K * 2
-                send = T_local.buf[:T_local.N * row_bytes]
-                if T_local.N != nmax:       # equal-sized contributions for all_gather_into_tensor
-                    pad = torch.zeros(nmax * row_bytes, dtype=torch.uint8, device=send.device)
-                    pad[:send.numel()] = send
-                    send = pad
-                return txt_emb, T_local, send.contiguous()
-            txt_emb, T_local, send = run('text', text_phase)
+                return txt_emb, _pad_rows(_flat_rows(txt_emb), nmax)
+            txt_emb, send = run('text', text_phase)
             mark('txt_tower')
-            row_bytes = T_local.K * 2
             work = None
             if comm:
-                if 'gathered' not in state or state['gathered'].numel() != world * nmax * row_bytes:
-                    state['gathered'] = torch.empty(world * nmax * row_bytes, dtype=torch.uint8, device=send.device)
+                shape = (world * nmax, send.shape[1])
+                if 'gathered' not in state or tuple(state['gathered'].shape) != shape:
+                    state['gathered'] = torch.empty(shape, dtype=send.dtype, device=send.device)
                 gathered = state['gathered']
                 work = dist.all_gather_into_tensor(gathered, send, group=group, async_op=True)     # overlaps the video tower
 
@@ -203,27 +248,26 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
                 return vis_emb, V
             vis_emb, V_local = run('video', video_phase)
             mark('vis_tower')
-            if work is None:
-                T_all = T_local
-            else:
+            if work is not None:
                 work.wait()
-            if work is None:
-                pass
-            elif all(hi - lo == nmax for lo, hi in sizes):
-                T_all = compute.operand_from_gathered(gathered, Nt, T_local.K, T_local)
-            else:
-                if runner is not None:
-                    raise NotImplementedError('uneven text shards need a compaction copy that is not captured; use eager mode')
-                parts = [gathered[r * nmax * row_bytes: r * nmax * row_bytes + (hi - lo) * row_bytes]
-                         for r, (lo, hi) in enumerate(sizes)]
-                T_all = compute.operand_from_gathered(torch.cat(parts), Nt, T_local.K, T_local)
             mark('all_gather_wait')
-        # ground-truth score from the shard that owns the column, then one GEMM that writes S and counts ranks
-        s_gt = run('s_gt', lambda: compute.row_dot_gt(T_all, V_local, gt, heads, v0))
+
+        # exact ground-truth score from the shard that owns the column, then one GEMM that writes S and counts ranks
+        def prep_phase():
+            if comm:
+                Et = _compact(gathered, sizes, nmax, heads)
+                T = compute.pack_gathered(Et)
+            elif hasattr(compute, 'embed_both'):
+                Et, T = Et_all, T_all
+            else:
+                Et = txt_emb
+                T = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
+            return compute.prepare(Et, vis_emb, T, V_local, gt, v0)
+        st = run('prep', prep_phase)
         if comm:
-            dist.all_reduce(s_gt, op=dist.ReduceOp.MAX, group=group)
+            dist.all_reduce(compute.s_gt_of(st), op=dist.ReduceOp.MAX, group=group)
         mark('s_gt')
-        S_local, count = run('sim', lambda: compute.sim_ranked(T_all, V_local, heads, gt, s_gt, v0, want_scores))
+        S_local, count = run('sim', lambda: compute.sim_ranked(st, want_scores))
         mark('sim_gemm')
         if comm:
             dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
@@ -247,22 +291,23 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
             if metrics_out is None and want_metrics:
                 metrics = compute.metrics(ranks)
         mark('metrics')
-    return {'S_local': S_local, 'col0': v0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb}
+    return {'S_local': S_local, 'col0': v0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb,
+            'rank_state': st}
 
 
 def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
                              want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False,
-                             finish_tag=''):
-    """The OTHER decomposition the path admits (not the default: BASELINE.json asks for video-row shards with an all-gather of
-    the text operand): rank g owns texts [t0, t1) end to end and the ROW block S[t0:t1, :]; videos are split for the embedding
-    stage only and ONE all-gather of the 16-bit VIDEO operand (Nv x K: 10 MB at C4 instead of 41 MB for the texts) gives every
-    rank all videos.  Every text then meets its ground-truth video locally, so neither the MAX all-reduce of s_gt nor the SUM
-    all-reduce of the counts is needed; the ranks (Nt int32) are all-gathered for the replicated metrics.
+                             finish_tag='', timer=None):
+    """The 'text' scheme of the module docstring: rank g owns texts [t0, t1) end to end and the ROW block S[t0:t1, :]; videos are
+    split for the embedding stage only and ONE all-gather of the fp32 VIDEO embeddings (Nv x K: a quarter of the text side at C4)
+    gives every rank all videos.  Every text then meets its ground-truth video locally, so neither the MAX all-reduce of s_gt
+    nor the SUM all-reduce of the counts is needed; the ranks (Nt int32) are all-gathered for the replicated metrics.
     Returns dict(S_local (t1-t0, Nv), row0, ranks (Nt,), metrics)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     comm = world > 1 or (force_collectives and dist.is_initialized())
     t0, t1 = shard_bounds(Nt, world, rank)
+    mark = timer.mark if timer is not None else (lambda name: None)
     run = runner if runner is not None else _eager
     state = state if state is not None else {}
     if runner is not None and metrics_out is None and want_metrics:
@@ -271,9 +316,8 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
     tsizes = [shard_bounds(Nt, world, r) for r in range(world)]
     vmax = max(hi - lo for lo, hi in vsizes)
     tmax = max(hi - lo for lo, hi in tsizes)
-    even = all(hi - lo == vmax for lo, hi in vsizes) and all(hi - lo == tmax for lo, hi in tsizes)
-    if runner is not None and comm and not even:
-        raise NotImplementedError('uneven shards need compaction copies that are not captured; use eager mode')
+    if hasattr(compute, 'set_unpacked'):
+        compute.set_unpacked('vis' if comm else None)
     with torch.no_grad():
         def towers():
             if hasattr(compute, 'embed_both'):
@@ -281,54 +325,58 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
             else:
                 txt_emb, vis_emb = compute.embed_text(txt_feats_local), compute.embed_video(vis_feats_local)
             T_local = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
+            if comm:
+                return txt_emb, vis_emb, T_local, None, _pad_rows(_flat_rows(vis_emb), vmax)
             V_local = compute.pack(vis_emb, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack(vis_emb)
-            if V_local.precision not in ('fp16', 'bf16'):
-                raise NotImplementedError("sharded evaluation gathers a single-plane 16-bit operand; precision '%s' is "
-                                          'single-GPU only for now' % V_local.precision)
-            row_bytes = V_local.K * 2
-            send = V_local.buf[:V_local.N * row_bytes]
-            if V_local.N != vmax:
-                pad = torch.zeros(vmax * row_bytes, dtype=torch.uint8, device=send.device)
-                pad[:send.numel()] = send
-                send = pad
-            return txt_emb, vis_emb, T_local, V_local, send.contiguous()
+            return txt_emb, vis_emb, T_local, V_local, None
         txt_emb, vis_emb, T_local, V_local, send = run('towers_t', towers)
-        row_bytes = V_local.K * 2
+        mark('towers')
         if comm:
-            if 'gathered_v' not in state or state['gathered_v'].numel() != world * vmax * row_bytes:
-                state['gathered_v'] = torch.empty(world * vmax * row_bytes, dtype=torch.uint8, device=send.device)
+            shape = (world * vmax, send.shape[1])
+            if 'gathered_v' not in state or tuple(state['gathered_v'].shape) != shape:
+                state['gathered_v'] = torch.empty(shape, dtype=send.dtype, device=send.device)
             gathered = state['gathered_v']
             dist.all_gather_into_tensor(gathered, send, group=group)
-            if even:
-                V_all = compute.operand_from_gathered(gathered, Nv, V_local.K, V_local)
-            else:
-                parts = [gathered[r * vmax * row_bytes: r * vmax * row_bytes + (hi - lo) * row_bytes] for r, (lo, hi) in enumerate(vsizes)]
-                V_all = compute.operand_from_gathered(torch.cat(parts), Nv, V_local.K, V_local)
-        else:
-            V_all = V_local
+        mark('all_gather_wait')
         gt_local = gt[t0:t1].contiguous()
 
         def rank_phase():
-            s_gt = compute.row_dot_gt(T_local, V_all, gt_local, heads, 0)
-            S_local, count = compute.sim_ranked(T_local, V_all, heads, gt_local, s_gt, 0, want_scores)
+            if comm:
+                Ev = _compact(gathered, vsizes, vmax, heads)
+                V = compute.pack_gathered(Ev)
+            else:
+                Ev, V = vis_emb, V_local
+            st = compute.prepare(txt_emb, Ev, T_local, V, gt_local, 0)
+            S_local, count = compute.sim_ranked(st, want_scores)
             mine = (count + 1).to(torch.int32)
-            if mine.numel() != tmax:
+            if comm and mine.numel() != tmax:
                 pad = torch.ones(tmax, dtype=torch.int32, device=mine.device)
                 pad[:mine.numel()] = mine
                 mine = pad
-            return S_local, mine.contiguous()
-        S_local, mine = run('rank_t', rank_phase)
+            return S_local, mine.contiguous(), st
+        S_local, mine, st = run('rank_t', rank_phase)
+        mark('sim_gemm')
         if comm:
             if 'gathered_r' not in state or state['gathered_r'].numel() != world * tmax:
                 state['gathered_r'] = torch.empty(world * tmax, dtype=torch.int32, device=mine.device)
             all_ranks = state['gathered_r']
             dist.all_gather_into_tensor(all_ranks, mine, group=group)
-            ranks = all_ranks if even else torch.cat([all_ranks[r * tmax: r * tmax + (hi - lo)] for r, (lo, hi) in enumerate(tsizes)])
         else:
-            ranks = mine[:Nt]
+            all_ranks = mine
+
+        def finish():
+            if comm and not all(hi - lo == tmax for lo, hi in tsizes):
+                ranks = torch.cat([all_ranks[r * tmax: r * tmax + (hi - lo)] for r, (lo, hi) in enumerate(tsizes)])
+            else:
+                ranks = all_ranks[:Nt]
+            if metrics_out is not None:
+                compute.metrics_async(ranks, metrics_out)
+            return ranks
+        ranks = run('finish_t' + finish_tag, finish)
+        mark('rank')
         metrics = None
-        if metrics_out is not None:
-            run('finish_t' + finish_tag, lambda: compute.metrics_async(ranks, metrics_out))
-        elif want_metrics:
+        if metrics_out is None and want_metrics:
             metrics = compute.metrics(ranks)
-    return {'S_local': S_local, 'row0': t0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb}
+        mark('metrics')
+    return {'S_local': S_local, 'row0': t0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb,
+            'rank_state': st}

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, FcSplitProblem, Plane, check, FcFusedProblem)
 
-__all__ = ['topk_rows', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -480,6 +480,98 @@ def row_dot_gt(T, V, gt_col, heads=1, col0=0, zero_count=None):
     _call('row_dot_gt', lib.laff_row_dot_gt, h, _ptr(T.buf), _ptr(V.buf), T.N, V.N, T.K, scale, PREC[T.precision], _ptr(gt_col),
           col0, _ptr(out), _ptr(zero_count))
     return out
+
+
+class RankState:
+    """What the exact-rank pipeline carries between its three launches (laff_rank_prepare -> laff_sim_gemm_banded ->
+    laff_rank_resolve): the exact ground-truth scores (fp64; all-reduce MAX them when videos are sharded), the two band vectors,
+    the count accumulator and the list of pairs inside the band."""
+
+    def __init__(self, Et, Ev, T, V, heads, gt_col, col0, s_gt64, band_t, band_v, count, pairs, pair_cap):
+        self.Et, self.Ev, self.T, self.V, self.heads, self.gt_col, self.col0 = Et, Ev, T, V, heads, gt_col, col0
+        self.s_gt64, self.band_t, self.band_v, self.count, self.pairs, self.pair_cap = s_gt64, band_t, band_v, count, pairs, pair_cap
+
+    def listed_pairs(self):
+        """(number of pairs the GEMM listed, overflow flag) -- synchronises; diagnostics only."""
+        h = self.pairs[:2].cpu()
+        return int(h[0]), bool(h[1])
+
+
+def _emb3(E, name):
+    _dev(E, name)
+    if E.dim() == 2:
+        E = E.unsqueeze(1)
+    if E.dim() != 3 or not E.is_contiguous():
+        raise ValueError('%s must be a contiguous (N, H, d) or (N, d) fp32 tensor' % name)
+    return E
+
+
+def default_pair_cap(Nt):
+    return max(1 << 20, 32 * int(Nt))
+
+
+def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None):
+    """First launch of the exact-rank pipeline.  Et (Nt, H, d) / Ev (Nv, H, d): the fp32 embeddings; T / V: the Packed GEMM
+    operands made from them; gt_col int32 (Nt,) ground-truth column of every text (global index; col0 = first column of this
+    video shard).  Returns a RankState."""
+    Et, Ev = _emb3(Et, 'Et'), _emb3(Ev, 'Ev')
+    Nt, H, d = Et.shape
+    Nv = Ev.shape[0]
+    if tuple(Ev.shape[1:]) != (H, d) or T.N != Nt or V.N != Nv or T.K != H * d or V.K != H * d:
+        raise ValueError('embeddings %s / %s do not match the operands (%d x %d, %d x %d)' % (tuple(Et.shape), tuple(Ev.shape), T.N, T.K, V.N, V.K))
+    if T.precision != V.precision or T.prescale != V.prescale:
+        raise ValueError('operands differ in precision or prescale')
+    _dev(gt_col, 'gt_col', torch.int32)
+    if gt_col.numel() != Nt or not gt_col.is_contiguous():
+        raise ValueError('gt_col must be a contiguous int32 vector of %d' % Nt)
+    dev = Et.device
+    cap = int(pair_cap) if pair_cap is not None else default_pair_cap(Nt)
+    s_gt64 = torch.empty((Nt,), device=dev, dtype=torch.float64)
+    band_t = torch.empty((max(Nt, 1),), device=dev, dtype=torch.float32)
+    band_v = torch.empty((max(Nv, 4),), device=dev, dtype=torch.float32)
+    count = torch.empty((Nt,), device=dev, dtype=torch.int32)
+    pairs = torch.empty((4 + 2 * cap,), device=dev, dtype=torch.int32)
+    lib, h = _context(dev)
+    _call('rank_prepare', lib.laff_rank_prepare, h, _ptr(Et), _ptr(Ev), _ptr(T.buf), _ptr(V.buf), Nt, Nv, H, d, PREC[T.precision],
+          float(T.prescale), _ptr(gt_col), int(col0), _ptr(s_gt64), _ptr(band_t), _ptr(band_v), _ptr(count), _ptr(pairs))
+    return RankState(Et, Ev, T, V, H, gt_col, int(col0), s_gt64, band_t, band_v, count, pairs, cap)
+
+
+def sim_gemm_banded(st, want_scores=True, out=None):
+    """Second launch: the similarity GEMM with the banded count (state.count, state.pairs are filled).  Returns S or None."""
+    T, V = st.T, st.V
+    dev = T.buf.device
+    S, lds = None, V.N
+    if want_scores:
+        S = out if out is not None else torch.empty((T.N, V.N), device=dev, dtype=torch.float32)
+        S, lds = _rows(S, 'out')
+        if tuple(S.shape) != (T.N, V.N):
+            raise ValueError('out must be (%d, %d)' % (T.N, V.N))
+    scale = 1.0 / (st.heads * T.prescale * V.prescale)
+    lib, h = _context(dev)
+    _call('sim_gemm', lib.laff_sim_gemm_banded, h, _ptr(T.buf), _ptr(V.buf), T.N, V.N, T.K, scale, PREC[T.precision], _ptr(S), lds,
+          _ptr(st.gt_col), st.col0, _ptr(st.s_gt64), _ptr(st.band_t), _ptr(st.band_v), _ptr(st.count), _ptr(st.pairs), st.pair_cap)
+    return S
+
+
+def rank_resolve(st, S=None):
+    """Third launch: exact re-score of the listed pairs; state.count (+ S) are final afterwards."""
+    lds = 0
+    if S is not None:
+        S, lds = _rows(S, 'S')
+    Nt, H, d = st.Et.shape
+    lib, h = _context(st.Et.device)
+    _call('rank_resolve', lib.laff_rank_resolve, h, _ptr(st.Et), _ptr(st.Ev), Nt, st.Ev.shape[0], H, d, _ptr(st.s_gt64), _ptr(st.count),
+          _ptr(S), lds, _ptr(st.pairs), st.pair_cap)
+    return st.count
+
+
+def exact_ranks(Et, Ev, T, V, gt_col, want_scores=True, col0=0):
+    """prepare -> banded GEMM -> resolve on one device.  Returns (S or None, count int32 (Nt,), RankState); ranks = count + 1."""
+    st = rank_prepare(Et, Ev, T, V, gt_col, col0)
+    S = sim_gemm_banded(st, want_scores)
+    rank_resolve(st, S)
+    return S, st.count, st
 
 
 def gather_gt(S, gt_col, col0=0):

@@ -29,15 +29,22 @@ def embed(model, vis_feats, txt_feats):
     return fin_v(), fin_t()
 
 
-def evaluate(model, vis_feats, txt_feats, gt, precision='fp16', write_scores=True, want_metrics=True):
+def evaluate(model, vis_feats, txt_feats, gt, precision='fp16', write_scores=True, want_metrics=True, exact=True):
     """One pass of the hot path on one GPU.  gt: int32 (Nt,) device tensor of ground-truth video columns.
-    write_scores=False skips materialising S (ranks only)."""
+    write_scores=False skips materialising S (ranks only).
+
+    exact=True (default): ranks are those of the exact cosine scores of the fp32 embeddings whatever the GEMM operand
+    precision (ops.exact_ranks: error-band count in the GEMM epilogue + exact re-score of the pairs inside the band) -- the
+    reference ranks on fp32 scores (predictor.py:232-244).  exact=False: ranks of the reduced-precision scores themselves."""
     with torch.no_grad():
         vis_emb, txt_emb = embed(model, vis_feats, txt_feats)
         heads = vis_emb.shape[1] if vis_emb.dim() == 3 else 1
         T = ops.pack_rows(txt_emb, True, 1e-13, precision)
         V = ops.pack_rows(vis_emb, True, 1e-13, precision)
-        if precision == 'fp32':
+        state = None
+        if exact:
+            S, count, state = ops.exact_ranks(txt_emb, vis_emb, T, V, gt, write_scores)
+        elif precision == 'fp32':
             S = ops.sim_gemm(T, V, heads=heads)
             s_gt = ops.gather_gt(S, gt)
             count = ops.rank_count(S, gt, s_gt)
@@ -50,4 +57,6 @@ def evaluate(model, vis_feats, txt_feats, gt, precision='fp16', write_scores=Tru
             metrics = ops.rank_metrics(count, base=1, ranks_out=ranks)
         else:
             ranks, metrics = count + 1, None
-    return RetrievalResult(S, ranks, metrics, vis_emb, txt_emb)
+    res = RetrievalResult(S, ranks, metrics, vis_emb, txt_emb)
+    res.rank_state = state
+    return res

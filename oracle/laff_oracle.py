@@ -205,6 +205,33 @@ def predict_blocked(txt_emb_batches, vis_emb_batches, Nt, Nv):
     return scores
 
 
+def txt2vis_matrix_f64(txt_embs, vis_embs):
+    """The INFINITELY PRECISE value of get_txt2vis_matrix on the given fp32 embeddings (model/model.py:1003-1016 on
+    loss.py:30-34): mean_h <t_h, v_h> / ((|t_h| + 1e-13 + 1e-14)(|v_h| + 1e-13 + 1e-14)) evaluated in float64 (products of fp32
+    values are exact in fp64).  The reference evaluates the same expression in fp32, i.e. this value +- ~1e-7; ranks taken on it are
+    the tie-free limit of the reference's ranks.  Used as the rank oracle for the exact-rank pipeline."""
+    t, v = np.asarray(txt_embs, dtype=np.float64), np.asarray(vis_embs, dtype=np.float64)
+    if t.ndim == 2:
+        t, v = t[:, None, :], v[:, None, :]
+    H = t.shape[1]
+    S = np.zeros((t.shape[0], v.shape[0]), np.float64)
+    for h in range(H):
+        tn = t[:, h, :] / (np.sqrt((t[:, h, :] ** 2).sum(axis=1, keepdims=True)) + (1e-13 + 1e-14))
+        vn = v[:, h, :] / (np.sqrt((v[:, h, :] ** 2).sum(axis=1, keepdims=True)) + (1e-13 + 1e-14))
+        S += tn @ vn.T
+    return S / H
+
+
+def count_ranks(S, gt_cols):
+    """rank[t] = 1 + #{v != gt : S[t, v] > S[t, gt]} (predictor.py:232-244 in count form, single ground truth per row)."""
+    S = np.asarray(S)
+    gt_cols = np.asarray(gt_cols).astype(np.int64)
+    sg = S[np.arange(S.shape[0]), gt_cols]
+    above = S > sg[:, None]
+    above[np.arange(S.shape[0]), gt_cols] = False
+    return above.sum(axis=1).astype(np.int64) + 1
+
+
 # ------------------------------------------------------------------------------------------------
 # a12-a14: ranks and metrics
 # ------------------------------------------------------------------------------------------------

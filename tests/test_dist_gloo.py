@@ -31,11 +31,12 @@ class OracleBackend:
         return torch.from_numpy(O.l2norm(np.tanh(f['x'].numpy() @ self.Wv)))
 
     def pack(self, E, layer=None):
+        E = E.reshape(E.shape[0], -1)
         h = E.to(torch.float16).contiguous()
         return Packed(h.view(torch.uint8).reshape(-1), E.shape[0], E.shape[1])
 
-    def operand_from_gathered(self, bufs, rows, K, like):
-        return Packed(bufs, rows, K)
+    def pack_gathered(self, E):
+        return self.pack(E)
 
     @staticmethod
     def _mat(p):
@@ -44,18 +45,28 @@ class OracleBackend:
     def sim(self, T, V, heads):
         return self._mat(T) @ self._mat(V).T
 
-    def row_dot_gt(self, T, V, gt, heads, col0):
-        S = self.sim(T, V, heads)
-        c = gt.long() - col0
-        ok = (c >= 0) & (c < S.shape[1])
-        out = torch.full((S.shape[0],), float('-inf'))
-        out[ok] = S[torch.arange(S.shape[0])[ok], c[ok]]
-        return out
+    class State:
+        pass
 
-    def sim_ranked(self, T, V, heads, gt, s_gt, col0, want_scores=True):
-        S = self.sim(T, V, heads)
-        cols = torch.arange(S.shape[1])[None, :] + col0
-        count = ((S > s_gt[:, None]) & (cols != gt.long()[:, None])).sum(dim=1).to(torch.int32)
+    def prepare(self, Et, Ev, T, V, gt, col0):
+        """exact ground-truth scores (float64) of the texts whose video is in this shard, -inf elsewhere"""
+        st = self.State()
+        st.Et, st.Ev, st.T, st.V, st.gt, st.col0 = Et, Ev, T, V, gt, col0
+        st.S64 = torch.from_numpy(O.txt2vis_matrix_f64(Et.reshape(Et.shape[0], -1).numpy(), Ev.reshape(Ev.shape[0], -1).numpy()))
+        c = gt.long() - col0
+        ok = (c >= 0) & (c < st.S64.shape[1])
+        st.s_gt64 = torch.full((st.S64.shape[0],), float('-inf'), dtype=torch.float64)
+        st.s_gt64[ok] = st.S64[torch.arange(st.S64.shape[0])[ok], c[ok]]
+        return st
+
+    def s_gt_of(self, st):
+        return st.s_gt64
+
+    def sim_ranked(self, st, want_scores=True):
+        """fp16-operand score block + counts of the EXACT scores above the exact ground-truth score"""
+        S = self.sim(st.T, st.V, 1)
+        cols = torch.arange(S.shape[1])[None, :] + st.col0
+        count = ((st.S64 > st.s_gt64[:, None]) & (cols != st.gt.long()[:, None])).sum(dim=1).to(torch.int32)
         return S, count
 
     def metrics(self, ranks):
@@ -120,6 +131,10 @@ def test_sharded_equals_single(world, tmp_path):
         np.testing.assert_allclose(z['metrics'], np.array(single['metrics']), rtol=0, atol=1e-12)
         cols.append(z['S'])
     np.testing.assert_allclose(np.concatenate(cols, axis=1), single['S_local'].numpy(), rtol=0, atol=1e-6)
+    xt, xv, gt, Wt, Wv = _problem()
+    b = OracleBackend(Wt, Wv)
+    want = O.count_ranks(O.txt2vis_matrix_f64(b.embed_text({'x': torch.from_numpy(xt)}).numpy(), b.embed_video({'x': torch.from_numpy(xv)}).numpy()), gt)
+    assert np.array_equal(single['ranks'].numpy(), want)
 
 
 def _worker_by_text(rank, world, port, out_dir):

@@ -650,3 +650,99 @@ def test_fuse_gather_plane_equals_separate_gather_fc(H, d, act):
     ref = O.multi_head_attention(np.stack([ref_plane, other, np.tile(clip, (1, H)) * sc + sh], axis=1), w.cpu().numpy(), b.cpu().numpy(),
                                  gw.cpu().numpy(), H, True, False)
     assert maxdiff(E_gat, ref) <= 5e-6
+
+
+# ---- exact ranks on a reduced-precision GEMM (laff_rank_prepare -> laff_sim_gemm_banded -> laff_rank_resolve) --------------
+def _exact_scores_f64(t, v):
+    """torch float64 statement of oracle.txt2vis_matrix_f64 on the device (the oracle itself checks it below at small sizes)."""
+    t, v = t.double(), v.double()
+    if t.dim() == 2:
+        t, v = t[:, None, :], v[:, None, :]
+    H = t.shape[1]
+    S = torch.zeros((t.shape[0], v.shape[0]), dtype=torch.float64, device=t.device)
+    for h in range(H):
+        tn = t[:, h] / (t[:, h].pow(2).sum(1, keepdim=True).sqrt() + (1e-13 + 1e-14))
+        vn = v[:, h] / (v[:, h].pow(2).sum(1, keepdim=True).sqrt() + (1e-13 + 1e-14))
+        S += tn @ vn.T
+    return S / H
+
+
+def _count_ranks(S, gt):
+    sg = S.gather(1, gt.long()[:, None])
+    above = S > sg
+    above[torch.arange(S.shape[0], device=S.device), gt.long()] = False
+    return above.sum(1).to(torch.int32) + 1
+
+
+@pytest.mark.parametrize('precision', ['fp16', 'bf16', 'fp16x3', 'bf16x3', 'fp32'])
+@pytest.mark.parametrize('Nt,Nv,H,d', [(700, 333, 1, 512), (513, 257, 8, 64), (1500, 1100, 2, 256), (64, 9, 1, 36)])
+def test_exact_ranks_equal_fp64_ranks(precision, Nt, Nv, H, d):
+    """Whatever the operand precision, count + 1 are the ranks of the exact (fp64) cosine scores of the fp32 embeddings, the band
+    really bounds the GEMM's error, the listed pairs are few, and the S that comes back recounts to the same ranks."""
+    from laff_amd import ops
+    from oracle import laff_oracle as O
+    g = rnd(1000 + Nt + H)
+    # clustered rows: many near ties around the ground-truth score (what makes a 16-bit GEMM mis-rank)
+    zc = g.normal(0, 1, (17, H, d))
+    t = (zc[g.integers(0, 17, Nt)] + 0.15 * g.normal(0, 1, (Nt, H, d))).astype(np.float32)
+    v = (zc[g.integers(0, 17, Nv)] + 0.15 * g.normal(0, 1, (Nv, H, d))).astype(np.float32)
+    v[Nv // 2] = v[Nv // 3]                                    # an exact duplicate video: a true tie, never counted
+    gt = dev(g.integers(0, Nv, Nt).astype(np.int32), torch.int32)
+    Et, Ev = dev(t), dev(v)
+    T, V = ops.pack_rows(Et, True, 1e-13, precision), ops.pack_rows(Ev, True, 1e-13, precision)
+    S, count, st = ops.exact_ranks(Et, Ev, T, V, gt)
+    S64 = _exact_scores_f64(Et, Ev)
+    want = _count_ranks(S64, gt)
+    assert torch.equal(count + 1, want), precision
+    if Nt * Nv <= 200000:                                      # the device fp64 statement against the numpy oracle
+        assert np.array_equal(want.cpu().numpy(), O.count_ranks(O.txt2vis_matrix_f64(t, v), gt.cpu().numpy()))
+    n_listed, overflow = st.listed_pairs()
+    assert not overflow
+    # the band is a true bound on the plain GEMM's error, and not a loose one
+    plain = ops.sim_gemm(T, V, heads=H)
+    band = st.band_t[:Nt, None] + st.band_v[None, :Nv]
+    ratio = ((plain.double() - S64).abs() / band.double()).max().item()
+    assert ratio <= 1.0, (precision, ratio)
+    assert n_listed <= int((((plain.double() - S64.gather(1, gt.long()[:, None])).abs() <= 2 * band.double()).sum().item())) + Nt
+    # S: exact value at the ground truth, rank-consistent everywhere
+    assert torch.equal(ops.gather_gt(S, gt), st.s_gt64.float())
+    assert torch.equal(ops.rank_count(S, gt, ops.gather_gt(S, gt)), count)
+    tol = {'fp16': 1e-4 * (1 + 22 / np.sqrt(d)), 'bf16': 8e-4 * (1 + 22 / np.sqrt(d)), 'fp16x3': 2e-6, 'bf16x3': 5e-6, 'fp32': 2e-6}[precision]
+    assert (S.double() - S64).abs().max().item() <= tol
+
+
+def test_exact_ranks_shard_semantics_and_overflow_flag():
+    """Video shards: s_gt64 is -inf for texts whose video lives elsewhere; MAX over shards + SUM of counts = the global ranks.
+    A pair list that is too small is reported, not silently truncated."""
+    from laff_amd import ops
+    g = rnd(77)
+    Nt, Nv, H, d = 900, 400, 1, 128
+    t = g.normal(0, 1, (Nt, H, d)).astype(np.float32)
+    v = (g.normal(0, 1, (Nv, H, d)) * 0.05 + g.normal(0, 1, (1, H, d))).astype(np.float32)      # near-identical videos: many ties
+    gt = dev(g.integers(0, Nv, Nt).astype(np.int32), torch.int32)
+    Et, Ev = dev(t), dev(v)
+    T = ops.pack_rows(Et, True, 1e-13, 'fp16')
+    want = _count_ranks(_exact_scores_f64(Et, Ev), gt)
+    bounds = [0, 130, 131, 400]
+    states = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        Evs = Ev[a:b].contiguous()
+        states.append(ops.rank_prepare(Et, Evs, T, ops.pack_rows(Evs, True, 1e-13, 'fp16'), gt, col0=a))
+    s_all = torch.stack([s.s_gt64 for s in states]).max(dim=0).values
+    gtc = gt.cpu().numpy()
+    for s, a, b in zip(states, bounds[:-1], bounds[1:]):
+        own = torch.from_numpy((gtc >= a) & (gtc < b)).to(DEV)
+        assert torch.isneginf(s.s_gt64[~own]).all() and torch.isfinite(s.s_gt64[own]).all()
+    total = torch.zeros(Nt, dtype=torch.int32, device=DEV)
+    for s in states:
+        s.s_gt64.copy_(s_all)
+        Sb = ops.sim_gemm_banded(s)
+        total += ops.rank_resolve(s, Sb)
+    assert torch.equal(total + 1, want)
+    # overflow: a list of 8 pairs cannot hold this problem's near ties
+    st = ops.rank_prepare(Et, Ev, T, ops.pack_rows(Ev, True, 1e-13, 'fp16'), gt, pair_cap=8)
+    ops.rank_resolve(st, ops.sim_gemm_banded(st))
+    n, overflow = st.listed_pairs()
+    assert n > 8 and overflow
+    with pytest.raises(RuntimeError, match='rank < 1'):
+        ops.rank_metrics(st.count, base=1)
