@@ -43,6 +43,19 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0, 0, 0, 0};
 
 constexpr int ROWB = 128;   // bytes of K per row per K-step
 
+// Similarity kernels only: a staging list for the pairs inside the error band, placed BEYOND the operand ring (the ring is still
+// being read when the first waves reach the epilogue).  Layout: {count, global base, -, -} then PAIR_LCAP x {row, col}.  One global
+// atomicAdd per TILE publishes the list: appending every pair with its own atomic on the one global counter serialised the whole
+// launch (92k pairs at C4 x ~12 ns = 1.1 ms for a 0.6 ms kernel).
+constexpr int PAIR_LCAP = 1024;
+constexpr int PAIR_LDS = 16 + PAIR_LCAP * 8;
+// slots per tile segment: half of the list is split evenly between the tiles, the other half takes the overflow
+__host__ __device__ __forceinline__ unsigned pair_chunk(unsigned pair_cap, unsigned ntiles) {
+    unsigned c = (pair_cap / 2u) / (ntiles ? ntiles : 1u);
+    c = c > (unsigned)PAIR_LCAP ? (unsigned)PAIR_LCAP : c;
+    return c & ~3u;                                                         // 0: everything goes through the counter
+}
+
 template <int WM_, int WN_, int WR_, int WC_>
 struct Cfg {
     static constexpr int WM = WM_, WN = WN_, WR = WR_, WC = WC_;
@@ -51,7 +64,7 @@ struct Cfg {
     static constexpr int OPB_R = TR * ROWB, OPB_C = TC * ROWB, STAGEB = OPB_R + OPB_C;
     static constexpr int SMEM = 2 * STAGEB;
     static constexpr int ITR = TR * 8 / THREADS, ITC = TC * 8 / THREADS;   // 16-byte chunks per thread per stage
-    static constexpr int WPS = (THREADS / 64) * ((160 * 1024) / SMEM) / 4;  // waves per SIMD the LDS budget admits
+    static constexpr int WPS = (THREADS / 64) * ((160 * 1024) / (SMEM + PAIR_LDS)) / 4;  // waves per SIMD the LDS budget admits
     static constexpr int PITCH = WN * 32 + 4;                        // epilogue slab: 32 rows x (WN*32) fp32 per wave
     static_assert(WN == 2 || WN == 4, "the epilogue store loop handles 64 or 128 output columns per wave");
     static_assert(THREADS / 64 * 32 * PITCH * 4 <= SMEM, "epilogue slabs must fit in the operand ring");
@@ -163,34 +176,126 @@ enum { EPI_SIM = 0, EPI_FC = 1 };
 
 template <int EPI, bool FULL, typename CF>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM][CF::WN], int r0, int c0, int wr, int wc,
-                                         int wave, int lane, char* smem) {
+                                         int wave, int lane, char* smem, const float (&bc_pre)[CF::WN / 2]) {
     constexpr int WM = CF::WM, WN = CF::WN, PITCH = CF::PITCH;
     const int l31 = lane & 31, hh = lane >> 5;
     float* slab = (float*)smem + wave * (32 * PITCH);
     const int cw0 = c0 + wc * (WN * 32);               // first output column of this wave
     const bool banded = EPI == EPI_SIM && a.count != nullptr && a.s_gt64 != nullptr;
     const bool counting = EPI == EPI_SIM && a.count != nullptr && !banded;
+    // banded count: the column part of the band as ONE value per wave (max over the wave's WN*32 columns): the per-element test is
+    // then a compare against a per-row constant, as cheap as the plain count
+    // (the band_c values were fetched before the K loop: a global load here would sit on the tile's critical path)
+    float bcmax = 0.0f;
+    unsigned* plist = (unsigned*)(smem + CF::SMEM);
+    const unsigned chunk = banded ? pair_chunk(a.pair_cap, gridDim.x) : 0u;
+    const size_t ovf_base = (size_t)gridDim.x * chunk;                      // the overflow region starts behind the tile segments
+    if (banded) {
+#pragma unroll
+        for (int i = 0; i < WN / 2; ++i) bcmax = fmaxf(bcmax, bc_pre[i]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) bcmax = fmaxf(bcmax, __shfl_xor(bcmax, o));
+    }
+    // per-row inputs of all WM row blocks up front: one L2 round trip instead of one per block (the atomics of a block keep the
+    // compiler from hoisting the next block's loads)
+    int gt_[WM];
+    float sg_[WM], eps_[WM];
+#pragma unroll
+    for (int tr = 0; tr < WM; ++tr) {
+        const int rr = r0 + wr * (WM * 32) + tr * 32 + l31;
+        const bool row_ok = FULL || rr < a.nR;
+        gt_[tr] = -1; sg_[tr] = 0.0f; eps_[tr] = 0.0f;
+        if (counting && row_ok) {
+            gt_[tr] = a.gt_col[rr] - a.col0;
+            sg_[tr] = a.s_gt[rr];
+        }
+        if (banded && row_ok) {
+            gt_[tr] = a.gt_col[rr] - a.col0;
+            sg_[tr] = (float)a.s_gt64[rr];
+            eps_[tr] = a.band_r[rr] + bcmax;
+        }
+    }
 #pragma unroll
     for (int tr = 0; tr < WM; ++tr) {
         const int rbase = r0 + wr * (WM * 32) + tr * 32;
         const int rr = rbase + l31;
         const bool row_ok = FULL || rr < a.nR;
         int cnt = 0;
-        int gt = -1;
-        float sg = 0.0f, eband = 0.0f;
-        if (counting && row_ok) {
-            gt = a.gt_col[rr] - a.col0;
-            sg = a.s_gt[rr];
-        }
-        if (banded && row_ok) {
-            gt = a.gt_col[rr] - a.col0;
-            sg = (float)a.s_gt64[rr];
-            eband = a.band_r[rr];
-        }
+        const int gt = gt_[tr];
+        const float sg = sg_[tr], eps = eps_[tr];
         float rscl = a.scale;
         if (EPI == EPI_FC && a.row_scale && row_ok) rscl *= a.row_scale[rr];
 #pragma unroll
         for (int tc = 0; tc < WN; ++tc) {
+            if (EPI == EPI_SIM && banded) {
+                // Exact-rank count (laff_rank_prepare / laff_rank_resolve), one 32x32 block (16 values per lane) at a time: a score
+                // further than the proven error band from the exact ground-truth score is decided here; a pair inside the band is
+                // staged for the list that laff_rank_resolve re-scores exactly (fp64 on the fp32 embeddings).  The ground-truth pair
+                // is recognised by index: it takes the exact value in S, is never counted and never listed.  ONE scalar branch
+                // per block guards the rare part (a branch per quad cost ~2k cycles per wave in s_cmp / s_cbranch latency).
+                const int cb = cw0 + tc * 32;
+                float vv[4][4];
+                const unsigned long long gtm = __builtin_amdgcn_ballot_w64((unsigned)(gt - cb) < 32u);   // ground truth in this block
+                unsigned long long anym = gtm;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = acc[tr][tc][4 * q + e] * rscl;
+                        vv[q][e] = x;
+                        const float dlt = x - sg;
+                        const bool in = FULL || (row_ok && cb + 8 * q + 4 * hh + e < a.nC);
+                        cnt += (in && dlt > eps) ? 1 : 0;
+                        anym |= __builtin_amdgcn_ballot_w64(in && __builtin_fabsf(dlt) <= eps);   // the compare's lane mask, scalar OR
+                    }
+                if (anym != 0ull) {                                          // ~1/3 of the blocks
+                    // (1) this lane's in-band elements as a bit mask (branch-free; element i = 4 q + e <-> bit i)
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int i = 15; i >= 0; --i) {
+                        const bool in = FULL || (row_ok && cb + 8 * (i >> 2) + 4 * hh + (i & 3) < a.nC);
+                        bits = (bits << 1) | ((in && __builtin_fabsf(vv[i >> 2][i & 3] - sg) <= eps) ? 1u : 0u);
+                    }
+                    // (2) the ground-truth element: exact value into S, never counted, never listed
+                    if (gtm != 0ull) {                                       // scalar branch, ~1/10 of the blocks
+                        const int j = gt - cb;                               // column inside the block, if 0 <= j < 32
+                        const bool mine = (unsigned)j < 32u && ((j >> 2) & 1) == hh && row_ok && (FULL || gt < a.nC);   // (a column of the tile's padding is nobody's ground truth)
+                        const int gi = mine ? (j >> 3) * 4 + (j & 3) : -1;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const bool isg = i == gi;
+                            cnt -= (isg && vv[i >> 2][i & 3] - sg > eps) ? 1 : 0;
+                            vv[i >> 2][i & 3] = isg ? sg : vv[i >> 2][i & 3];
+                        }
+                        if (mine) bits &= ~(1u << gi);
+                    }
+                    // (3) stage the in-band pairs: one loop trip per flagged element of the busiest lane (usually one)
+                    while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
+                        if (bits != 0u) {
+                            const int i = __builtin_ctz(bits);
+                            bits &= bits - 1u;
+                            const unsigned cc = (unsigned)(cb + 8 * (i >> 2) + 4 * hh + (i & 3));
+                            const unsigned ls = atomicAdd(plist, 1u);        // LDS
+                            if (ls < (unsigned)PAIR_LCAP) {
+                                plist[4 + 2 * ls] = (unsigned)rr;
+                                plist[5 + 2 * ls] = cc;
+                            } else {                                         // staging list full: straight to the global list
+                                const size_t slot = ovf_base + atomicAdd(a.pairs, 1u);
+                                if (slot < a.pair_cap) {
+                                    a.pairs[4 + 2 * slot] = (unsigned)rr;
+                                    a.pairs[5 + 2 * slot] = cc;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (a.out) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *(float4*)(slab + l31 * PITCH + tc * 32 + 8 * q + 4 * hh) = make_float4(vv[q][0], vv[q][1], vv[q][2], vv[q][3]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = tc * 32 + 8 * q + 4 * hh;          // column inside the wave's 64
@@ -241,45 +346,6 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
                         cnt += (in && v[e] > sg) ? 1 : 0;
                     }
                 }
-                if (banded) {
-                    // Exact-rank count (laff_rank_prepare / laff_rank_resolve): a score further than the proven error band from
-                    // the exact ground-truth score is decided here; a pair inside the band is appended to the list that
-                    // laff_rank_resolve re-scores exactly (fp64 on the fp32 embeddings).  The ground-truth pair is inside its own
-                    // band by construction: it is recognised by index, takes the exact value in S and is never listed.
-                    float bc[4] = {0, 0, 0, 0};
-                    if (FULL || cc + 3 < a.nC) {
-                        *(float4*)bc = *(const float4*)(a.band_c + cc);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (cc + e < a.nC) bc[e] = a.band_c[cc + e];
-                    }
-                    bool any = (unsigned)(gt - cc) < 4u;                     // the ground-truth column is in this quad
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dlt = v[e] - sg, eps = eband + bc[e];
-                        const bool in = FULL || (row_ok && cc + e < a.nC);
-                        cnt += (in && dlt > eps) ? 1 : 0;
-                        any |= in && __builtin_fabsf(dlt) <= eps;
-                    }
-                    if (__builtin_amdgcn_ballot_w64(any) != 0ull) {          // rare: ~1e-4 of the pairs + one quad per row
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float dlt = v[e] - sg, eps = eband + bc[e];
-                            const bool in = FULL || (row_ok && cc + e < a.nC);
-                            if (in && cc + e == gt) {
-                                cnt -= (dlt > eps) ? 1 : 0;                  // never counted, whatever its approximate value
-                                v[e] = sg;
-                            } else if (in && __builtin_fabsf(dlt) <= eps) {
-                                const unsigned slot = atomicAdd(a.pairs, 1u);
-                                if (slot < a.pair_cap) {
-                                    a.pairs[4 + 2 * (size_t)slot] = (unsigned)rr;
-                                    a.pairs[5 + 2 * (size_t)slot] = (unsigned)(cc + e);
-                                }
-                            }
-                        }
-                    }
-                }
                 if (a.out) *(float4*)(slab + l31 * PITCH + cl) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
@@ -314,6 +380,30 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
                 }
             }
             __builtin_amdgcn_wave_barrier();            // slab is rewritten by the next 32-row block
+        }
+    }
+    if (banded) {
+        // Publish this tile's staged pairs WITHOUT a returning atomic (its ~1-2 us round trip at the very end of the tile is dead
+        // time for the whole CU): tile b owns the fixed segment [b * chunk, (b + 1) * chunk) of the list; unused slots are marked
+        // invalid.  Only a tile with more than `chunk` pairs appends the excess behind the segments with the global counter.
+        __syncthreads();
+        const unsigned n = min(plist[0], (unsigned)PAIR_LCAP);
+        const size_t seg = (size_t)blockIdx.x * chunk;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.pairs[2] = gridDim.x * chunk; a.pairs[3] = chunk; }
+        for (unsigned i = threadIdx.x; i < chunk; i += CF::THREADS) {
+            const bool have = i < n;
+            a.pairs[4 + 2 * (seg + i)] = have ? plist[4 + 2 * i] : 0xffffffffu;
+            a.pairs[5 + 2 * (seg + i)] = have ? plist[5 + 2 * i] : 0u;
+        }
+        if (n > chunk) {                                                    // block-uniform, rare
+            if (threadIdx.x == 0) plist[1] = atomicAdd(a.pairs, n - chunk);
+            __syncthreads();
+            const size_t base = ovf_base + plist[1];
+            for (unsigned i = chunk + threadIdx.x; i < n; i += CF::THREADS)
+                if (base + (i - chunk) < a.pair_cap) {
+                    a.pairs[4 + 2 * (base + (i - chunk))] = plist[4 + 2 * i];
+                    a.pairs[5 + 2 * (base + (i - chunk))] = plist[5 + 2 * i];
+                }
         }
     }
 }
@@ -421,6 +511,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
 #pragma unroll
     for (int ks = 0; ks < ROWB / 32; ++ks) xk[ks] = (unsigned)(((2 * ks + hh) ^ ((l31 >> 1) & 7)) * 16);
 
+    // column part of the error band of the banded count (EPI_SIM): fetched here, used after the K loop
+    float bc_pre[WN / 2];
+#pragma unroll
+    for (int i = 0; i < WN / 2; ++i) {
+        bc_pre[i] = 0.0f;
+        if constexpr (EPI == EPI_SIM) {
+            const int c = c0 + wc * (WN * 32) + i * 64 + lane;
+            if (a.s_gt64 && a.count && c < a.nC) bc_pre[i] = a.band_c[c];
+        }
+    }
     TRACE(1);
     if constexpr (STG == 2) {
         // ---- software-pipelined K loop (fast staging) ---------------------------------------------------------------
@@ -620,8 +720,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
     TRACE(5);
     const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
                       ((((uintptr_t)a.out) & 15) == 0);
-    if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
-    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, bc_pre);
+    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, bc_pre);
     TRACE(6);
 #undef TRACE
 }
@@ -802,6 +902,15 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     using I4 = std::integral_constant<int, 4>;
     using I6 = std::integral_constant<int, 6>;
 
+    float bc_pre[WN / 2];
+#pragma unroll
+    for (int i = 0; i < WN / 2; ++i) {
+        bc_pre[i] = 0.0f;
+        if constexpr (EPI == EPI_SIM) {
+            const int c = c0 + wc * (WN * 32) + i * 64 + lane;
+            if (a.s_gt64 && a.count && c < a.nC) bc_pre[i] = a.band_c[c];
+        }
+    }
     // prologue: stage 0 landed and visible, stage 1 in flight, operands of the first B group (C_lo, R_hi of slice 0) in flight
     fill_begin(0, 0);
     if constexpr (RF32) xload();
@@ -883,8 +992,8 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     __syncthreads();                                   // every wave is done reading the operand ring
     const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
                       ((((uintptr_t)a.out) & 15) == 0);
-    if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
-    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, bc_pre);
+    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, bc_pre);
 }
 
 template <int MODE>
@@ -893,6 +1002,7 @@ __global__ __launch_bounds__(CfgX3::THREADS, CfgX3::WPS) void gemm_nt_x3_kernel(
     const int tiles_r = (a.nR + CfgX3::TR - 1) / CfgX3::TR, tiles_c = (a.nC + CfgX3::TC - 1) / CfgX3::TC;
     int r0, c0;
     tile_origin<CfgX3>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), r0, c0);
+    if (threadIdx.x == 0) *(unsigned*)(smem + CfgX3::SMEM) = 0u;            // pair staging counter (ordered by the K loop's barriers)
     gemm_tile_x3<MODE, EPI_SIM>(a, r0, c0, smem);
 }
 
@@ -936,6 +1046,7 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_kernel(GemmArgs 
     const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
     int r0, c0;
     tile_origin<CF>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), r0, c0);
+    if (threadIdx.x == 0) *(unsigned*)(smem + CF::SMEM) = 0u;               // pair staging counter (ordered by the K loop's barriers)
     gemm_tile<MODE, STG, CF, EPI_SIM>(a, r0, c0, smem);
 }
 
@@ -964,11 +1075,11 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t st) {
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
     static bool attr_set = false;          // once per instantiation; also keeps the call out of HIP-graph captures
     if (!attr_set) {
-        hipError_t e = set_smem(gemm_nt_kernel<MODE, STG, CF>, CF::SMEM);
+        hipError_t e = set_smem(gemm_nt_kernel<MODE, STG, CF>, CF::SMEM + PAIR_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<MODE, STG, CF>), dim3((unsigned)nb), dim3(CF::THREADS), CF::SMEM, st, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<MODE, STG, CF>), dim3((unsigned)nb), dim3(CF::THREADS), CF::SMEM + PAIR_LDS, st, a);
     return hipGetLastError();
 }
 
@@ -1084,11 +1195,11 @@ static hipError_t launch_x3(const GemmArgs& a, hipStream_t st) {
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = set_smem(gemm_nt_x3_kernel<MODE>, CfgX3::SMEM);
+        hipError_t e = set_smem(gemm_nt_x3_kernel<MODE>, CfgX3::SMEM + PAIR_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_x3_kernel<MODE>), dim3((unsigned)nb), dim3(CfgX3::THREADS), CfgX3::SMEM, st, a);
+    hipLaunchKernelGGL((gemm_nt_x3_kernel<MODE>), dim3((unsigned)nb), dim3(CfgX3::THREADS), CfgX3::SMEM + PAIR_LDS, st, a);
     return hipGetLastError();
 }
 

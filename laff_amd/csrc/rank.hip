@@ -171,81 +171,106 @@ hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K
 //                         truncation, 2^-22 the final scaling and the fp32 copy of s_gt64);
 //   * the GEMM epilogue decides every pair outside the band and lists the pairs inside it (gemm_nt.hip);
 //   * laff_rank_resolve  re-scores the listed pairs with exact() and fixes count / S.
-// One wavefront per row / pair; lanes own float4 columns {256 j + 4 lane}.
-__device__ __forceinline__ double wave_sum_f64(double v) {
+// Rows / pairs are handled by GROUPS OF 16 LANES (4 per wavefront): lane sl of a group owns the float4 columns {64 j + 4 sl}.
+// Both kernels are latency-bound (a few KB per row, then a reduction), so 8 independent 16-byte loads per lane and a 4-step
+// reduction beat one wavefront per row; 95k listed pairs at C4 are 24k wavefronts instead of 95k.
+constexpr int RG = 16;                         // lanes per row / pair
+__device__ __forceinline__ double group_sum_f64(double v) {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = RG / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float group_sum_f32(float v) {
+#pragma unroll
+    for (int o = RG / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
 constexpr double COS_EPS = 1e-13 + 1e-14;      // loss.cosine_sim -> l2norm(eps=1e-13): X / (norm + eps + 1e-14)  (loss.py:8-13,30-34)
 
-// every lane returns the same value; identical arithmetic wherever it is called, so equal rows give equal scores
-__device__ __forceinline__ double exact_cos(const float* __restrict__ t, const float* __restrict__ v, int H, int d, int lane) {
+// every lane of the group returns the same value; identical arithmetic (lane -> column map, fma order, reduction tree) wherever it
+// is called, so equal rows give bit-equal scores: a duplicate of the ground-truth video ties with it exactly and is not counted
+__device__ __forceinline__ double exact_cos(const float* __restrict__ t, const float* __restrict__ v, int H, int d, int sl) {
     double s = 0.0;
     for (int h = 0; h < H; ++h) {
         const float* th = t + (long)h * d;
         const float* vh = v + (long)h * d;
         double tt = 0.0, vv = 0.0, tv = 0.0;
-        for (int c = lane * 4; c < d; c += 256) {
+        for (int c = sl * 4; c < d; c += RG * 4) {
             const float4 a = *(const float4*)(th + c), b = *(const float4*)(vh + c);
             const double ax = a.x, ay = a.y, az = a.z, aw = a.w, bx = b.x, by = b.y, bz = b.z, bw = b.w;
             tt = fma(ax, ax, tt); tt = fma(ay, ay, tt); tt = fma(az, az, tt); tt = fma(aw, aw, tt);
             vv = fma(bx, bx, vv); vv = fma(by, by, vv); vv = fma(bz, bz, vv); vv = fma(bw, bw, vv);
             tv = fma(ax, bx, tv); tv = fma(ay, by, tv); tv = fma(az, bz, tv); tv = fma(aw, bw, tv);
         }
-        tt = wave_sum_f64(tt); vv = wave_sum_f64(vv); tv = wave_sum_f64(tv);
+        tt = group_sum_f64(tt); vv = group_sum_f64(vv); tv = group_sum_f64(tv);
         s += tv / ((sqrt(tt) + COS_EPS) * (sqrt(vv) + COS_EPS));
     }
     return s / (double)H;
 }
 
-// q^2 = sum_k (operand[k] / prescale - e[k] / (|e_h| + eps))^2 over the whole row; PREC as LAFF_PREC_*
+// 4 operand values of row `row` at column k (hi + lo for a split operand), PREC as LAFF_PREC_*
 template <int PREC>
-__device__ __forceinline__ float quant_err2(const float* __restrict__ e, const void* __restrict__ op, long row, long nrows, int H,
-                                            int d, float inv_prescale, int lane) {
-    const long K = (long)H * d;
-    float q2 = 0.f;
-    for (int h = 0; h < H; ++h) {
-        const float* eh = e + (long)h * d;
-        double nn = 0.0;
-        for (int c = lane * 4; c < d; c += 256) {
-            const float4 a = *(const float4*)(eh + c);
-            nn = fma((double)a.x, (double)a.x, nn); nn = fma((double)a.y, (double)a.y, nn);
-            nn = fma((double)a.z, (double)a.z, nn); nn = fma((double)a.w, (double)a.w, nn);
-        }
-        const double inv = 1.0 / (sqrt(wave_sum_f64(nn)) + COS_EPS);
-        for (int c = lane * 4; c < d; c += 256) {
-            const float4 a = *(const float4*)(eh + c);
-            const float ref[4] = {(float)(a.x * inv), (float)(a.y * inv), (float)(a.z * inv), (float)(a.w * inv)};
-            float x[4];
-            const long k = row * K + (long)h * d + c;
-            if constexpr (PREC == LAFF_PREC_FP32) {
-                const float4 o = *(const float4*)((const float*)op + k);
-                x[0] = o.x; x[1] = o.y; x[2] = o.z; x[3] = o.w;
-            } else {
-                auto cvt = [](uint16_t b) -> float {
-                    if constexpr (PREC == LAFF_PREC_BF16 || PREC == LAFF_PREC_BF16X3) return __uint_as_float((unsigned)b << 16);
-                    else { _Float16 f; __builtin_memcpy(&f, &b, 2); return (float)f; }
-                };
-                const uint2 o = *(const uint2*)((const uint16_t*)op + k);
-                x[0] = cvt((uint16_t)o.x); x[1] = cvt((uint16_t)(o.x >> 16)); x[2] = cvt((uint16_t)o.y); x[3] = cvt((uint16_t)(o.y >> 16));
-                if constexpr (PREC == LAFF_PREC_FP16X3 || PREC == LAFF_PREC_BF16X3) {
-                    const uint2 l = *(const uint2*)((const uint16_t*)op + nrows * K + k);
-                    x[0] += cvt((uint16_t)l.x); x[1] += cvt((uint16_t)(l.x >> 16)); x[2] += cvt((uint16_t)l.y); x[3] += cvt((uint16_t)(l.y >> 16));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float dl = fmaf(x[i], inv_prescale, -ref[i]);
-                q2 = fmaf(dl, dl, q2);
-            }
+__device__ __forceinline__ void load_operand4(const void* __restrict__ op, long k, long plane, float (&x)[4]) {
+    if constexpr (PREC == LAFF_PREC_FP32) {
+        const float4 o = *(const float4*)((const float*)op + k);
+        x[0] = o.x; x[1] = o.y; x[2] = o.z; x[3] = o.w;
+    } else {
+        auto cvt = [](uint16_t b) -> float {
+            if constexpr (PREC == LAFF_PREC_BF16 || PREC == LAFF_PREC_BF16X3) return __uint_as_float((unsigned)b << 16);
+            else { _Float16 f; __builtin_memcpy(&f, &b, 2); return (float)f; }
+        };
+        const uint2 o = *(const uint2*)((const uint16_t*)op + k);
+        x[0] = cvt((uint16_t)o.x); x[1] = cvt((uint16_t)(o.x >> 16)); x[2] = cvt((uint16_t)o.y); x[3] = cvt((uint16_t)(o.y >> 16));
+        if constexpr (PREC == LAFF_PREC_FP16X3 || PREC == LAFF_PREC_BF16X3) {
+            const uint2 l = *(const uint2*)((const uint16_t*)op + plane + k);
+            x[0] += cvt((uint16_t)l.x); x[1] += cvt((uint16_t)(l.x >> 16)); x[2] += cvt((uint16_t)l.y); x[3] += cvt((uint16_t)(l.y >> 16));
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) q2 += __shfl_xor(q2, o);
-    return q2;
 }
+
+// ONE pass over a row: q^2 = sum_k (x_k - e_k / n_h)^2 with x = operand / prescale and n_h = |e_h| + eps, expanded as
+// xx - 2 xe / n + ee / n^2 per head with the three sums in fp64 (the terms cancel to ~1e-8 of their size; fp64 leaves 1e-16), and --
+// WITH_GT -- the exact cosine against the ground-truth row v in the same loop.  tt / vv / tv use exactly exact_cos()'s lane map, fma
+// order and reduction tree, so the value is bit-identical to what laff_rank_resolve computes for the same two rows.
+template <int PREC, bool WITH_GT>
+__device__ __forceinline__ float row_pass(const float* __restrict__ e, const void* __restrict__ op, long row, long nrows, int H, int d,
+                                          double inv_prescale, int sl, const float* __restrict__ v, double* cos_out) {
+    const long K = (long)H * d;
+    double q2 = 0.0, s = 0.0;
+    for (int h = 0; h < H; ++h) {
+        const float* eh = e + (long)h * d;
+        double tt = 0.0, vv = 0.0, tv = 0.0, xx = 0.0, xe = 0.0;
+#pragma unroll 4
+        for (int c = sl * 4; c < d; c += RG * 4) {
+            const float4 a = *(const float4*)(eh + c);
+            float x[4];
+            load_operand4<PREC>(op, row * K + (long)h * d + c, nrows * K, x);
+            const double ax = a.x, ay = a.y, az = a.z, aw = a.w;
+            tt = fma(ax, ax, tt); tt = fma(ay, ay, tt); tt = fma(az, az, tt); tt = fma(aw, aw, tt);
+            if constexpr (WITH_GT) {
+                const float4 b = *(const float4*)(v + (long)h * d + c);
+                const double bx = b.x, by = b.y, bz = b.z, bw = b.w;
+                vv = fma(bx, bx, vv); vv = fma(by, by, vv); vv = fma(bz, bz, vv); vv = fma(bw, bw, vv);
+                tv = fma(ax, bx, tv); tv = fma(ay, by, tv); tv = fma(az, bz, tv); tv = fma(aw, bw, tv);
+            }
+            const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+            xx = fma(x0, x0, xx); xx = fma(x1, x1, xx); xx = fma(x2, x2, xx); xx = fma(x3, x3, xx);
+            xe = fma(x0, ax, xe); xe = fma(x1, ay, xe); xe = fma(x2, az, xe); xe = fma(x3, aw, xe);
+        }
+        tt = group_sum_f64(tt);
+        if constexpr (WITH_GT) { vv = group_sum_f64(vv); tv = group_sum_f64(tv); }
+        xx = group_sum_f64(xx); xe = group_sum_f64(xe);
+        const double n = sqrt(tt) + COS_EPS;
+        if constexpr (WITH_GT) s += tv / (n * (sqrt(vv) + COS_EPS));
+        const double inv = 1.0 / n;
+        q2 += fmax(xx * inv_prescale * inv_prescale - 2.0 * inv * inv_prescale * xe + inv * inv * tt, 0.0);
+    }
+    if constexpr (WITH_GT) *cos_out = s / (double)H;
+    return (float)sqrt(q2);
+}
+
+constexpr int PREP_ROWS = 256 / RG;            // rows per 256-thread block
 
 template <int PREC>
 __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restrict__ Et, const float* __restrict__ Ev,
@@ -254,36 +279,44 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
                                                            int col0, double* __restrict__ s_gt64, float* __restrict__ band_t,
                                                            float* __restrict__ band_v, int* __restrict__ zero_count,
                                                            unsigned* __restrict__ pairs) {
-    const int lane = threadIdx.x & 63;
+    const int sl = threadIdx.x & (RG - 1), grp = threadIdx.x / RG;
     const long K = (long)H * d;
-    const long tblocks = ((long)Nt + 3) / 4;
+    const long tblocks = ((long)Nt + PREP_ROWS - 1) / PREP_ROWS;
     if (blockIdx.x == 0 && threadIdx.x < 4 && pairs) pairs[threadIdx.x] = 0u;       // pair counter + overflow flag
     const float rsqrt_h = 1.0f / sqrtf((float)H);
     if ((long)blockIdx.x < tblocks) {
-        const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (t >= Nt) return;
-        if (zero_count && lane == 0) zero_count[t] = 0;
+        const long t0 = (long)blockIdx.x * PREP_ROWS + grp;
+        const bool ok = t0 < Nt;
+        const long t = ok ? t0 : Nt - 1;                       // idle groups shadow the last row (shuffles stay convergent)
+        if (ok && zero_count && sl == 0) zero_count[t] = 0;
         const float* e = Et + t * K;
-        const float q = sqrtf(quant_err2<PREC>(e, T, t, Nt, H, d, inv_prescale, lane));
         const int c = gt_col[t] - col0;
+        const bool own = c >= 0 && c < Nv;
         double sg = -INFINITY;
-        if (c >= 0 && c < Nv) sg = exact_cos(e, Ev + (long)c * K, H, d, lane);
-        if (lane == 0) {
+        float q;
+        if (__builtin_amdgcn_ballot_w64(own) != 0ull) {            // wave-uniform: some group of this wavefront owns its column
+            q = row_pass<PREC, true>(e, T, t, Nt, H, d, (double)inv_prescale, sl, Ev + (long)(own ? c : 0) * K, &sg);
+            if (!own) sg = -INFINITY;
+        } else {
+            q = row_pass<PREC, false>(e, T, t, Nt, H, d, (double)inv_prescale, sl, nullptr, nullptr);
+        }
+        if (ok && sl == 0) {
             s_gt64[t] = sg;
             band_t[t] = q * rsqrt_h * (1.0f + unit) * 1.0001f + c_acc;
         }
     } else {
-        const long v = ((long)blockIdx.x - tblocks) * 4 + (threadIdx.x >> 6);
-        if (v >= Nv) return;
-        const float q = sqrtf(quant_err2<PREC>(Ev + v * K, V, v, Nv, H, d, inv_prescale, lane));
-        if (lane == 0) band_v[v] = q * rsqrt_h * 1.0001f;
+        const long v0 = ((long)blockIdx.x - tblocks) * PREP_ROWS + grp;
+        const bool ok = v0 < Nv;
+        const long v = ok ? v0 : Nv - 1;
+        const float q = row_pass<PREC, false>(Ev + v * K, V, v, Nv, H, d, (double)inv_prescale, sl, nullptr, nullptr);
+        if (ok && sl == 0) band_v[v] = q * rsqrt_h * 1.0001f;
     }
 }
 
 hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
                                int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t,
                                float* band_v, int* zero_count, unsigned* pairs, hipStream_t st) {
-    const long grid = ((long)Nt + 3) / 4 + ((long)Nv + 3) / 4;
+    const long grid = ((long)Nt + PREP_ROWS - 1) / PREP_ROWS + ((long)Nv + PREP_ROWS - 1) / PREP_ROWS;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
     const float inv = 1.0f / prescale;
     // fp32 accumulation of the exact products: K terms (3K for a hi/lo split, plus its dropped lo*lo term <= 2^-22), 2^-23 each
@@ -305,28 +338,29 @@ hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, 
     return hipGetLastError();
 }
 
-// one wavefront per listed pair, grid-stride.  count[row] += 1 when the exact score beats the exact ground-truth score; S (optional)
-// takes the fp32 value of the exact score, nudged by one ulp where rounding to fp32 would hide a strict inequality, so that ranks
-// recounted from S (laff_rank_count) equal the ranks produced here.  More pairs than the list holds: overflow flag + count[0]
-// poisoned (rank < 1 trips the error flag of laff_rank_metrics*).
+// one 16-lane group per listed pair.  The list (written by the banded GEMM epilogue): header {n_overflow, overflow flag, A, chunk},
+// then A = tiles * chunk slots in per-tile segments (valid pairs first, the rest marked row = 0xffffffff), then n_overflow pairs
+// appended with the counter.  A wavefront takes a segment (4 pairs at a time, until the first invalid slot), then a share of the
+// overflow region.  count[row] += 1 when the exact score beats the exact ground-truth score; S (optional) takes the fp32 value of the
+// exact score, nudged by one ulp where rounding to fp32 would hide a strict inequality, so that ranks recounted from S
+// (laff_rank_count) equal the ranks produced here.  More pairs than the list holds: overflow flag + count[0] poisoned (rank < 1 trips
+// the error flag of laff_rank_metrics*).
 __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d,
                                                            const double* __restrict__ s_gt64, int* __restrict__ count,
                                                            float* __restrict__ S, long lds, unsigned* __restrict__ pairs,
                                                            unsigned pair_cap) {
-    const int lane = threadIdx.x & 63;
-    const unsigned total = pairs[0];
+    const int sl = threadIdx.x & (RG - 1), sub = (threadIdx.x / RG) & 3;
     const long K = (long)H * d;
-    if (total > pair_cap) {
+    const unsigned n_over = pairs[0], regA = pairs[2], chunk = pairs[3];
+    const unsigned long long room = pair_cap > regA ? pair_cap - regA : 0u;
+    if (n_over > room) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[1] = 1u; count[0] = -0x40000000; }
     }
-    const unsigned n = total < pair_cap ? total : pair_cap;
-    const unsigned stride = gridDim.x * 4u;
-    for (unsigned i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += stride) {
-        const unsigned r = pairs[4 + 2 * (size_t)i], c = pairs[5 + 2 * (size_t)i];
-        const double ex = exact_cos(Et + (long)r * K, Ev + (long)c * K, H, d, lane);
+    auto one = [&](unsigned r, unsigned c, bool ok) {
+        const double ex = exact_cos(Et + (long)r * K, Ev + (long)c * K, H, d, sl);
         const double sg = s_gt64[r];
         const bool above = ex > sg;
-        if (lane == 0) {
+        if (ok && sl == 0) {
             if (above) atomicAdd(count + r, 1);
             if (S) {
                 float f = (float)ex;
@@ -335,6 +369,24 @@ __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restri
                 S[(long)r * lds + c] = f;
             }
         }
+    };
+    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    const unsigned ntiles = chunk ? regA / chunk : 0u;
+    for (unsigned b = wave; b < ntiles; b += nwaves) {                       // wave-uniform loops: the shuffles stay convergent
+        const size_t seg = (size_t)b * chunk;
+        for (unsigned i0 = 0; i0 < chunk; i0 += 4) {
+            const unsigned r = pairs[4 + 2 * (seg + i0 + sub)], c = pairs[5 + 2 * (seg + i0 + sub)];
+            const bool ok = r != 0xffffffffu;
+            if (__builtin_amdgcn_ballot_w64(ok) == 0ull) break;              // valid pairs come first in a segment
+            one(ok ? r : 0u, ok ? c : 0u, ok);
+        }
+    }
+    const unsigned n = (unsigned)(n_over < room ? n_over : room);
+    for (unsigned i0 = wave * 4u; i0 < n; i0 += nwaves * 4u) {
+        const unsigned i = i0 + sub;
+        const bool ok = i < n;
+        const size_t j = (size_t)regA + (ok ? i : n - 1);
+        one(pairs[4 + 2 * j], pairs[5 + 2 * j], ok);
     }
 }
 

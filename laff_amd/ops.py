@@ -492,9 +492,20 @@ class RankState:
         self.s_gt64, self.band_t, self.band_v, self.count, self.pairs, self.pair_cap = s_gt64, band_t, band_v, count, pairs, pair_cap
 
     def listed_pairs(self):
-        """(number of pairs the GEMM listed, overflow flag) -- synchronises; diagnostics only."""
-        h = self.pairs[:2].cpu()
-        return int(h[0]), bool(h[1])
+        """(number of pairs the GEMM listed, overflow flag) -- synchronises; diagnostics only.  List layout: header {overflow
+        count, overflow flag, A, chunk}, A slots of per-tile segments (unused slots have row 0xffffffff), then the overflow pairs."""
+        h = self.pairs[:4].cpu().tolist()
+        n_over, flag, reg_a = h[0] & 0xffffffff, h[1], h[2] & 0xffffffff
+        valid = int((self.pairs[4:4 + 2 * reg_a:2] != -1).sum()) if reg_a else 0
+        return valid + n_over, bool(flag)
+
+    def pair_indices(self):
+        """(n, 2) int64 tensor of the listed (row, col) pairs -- synchronises; diagnostics / tests only."""
+        h = self.pairs[:4].cpu().tolist()
+        n_over, reg_a = h[0] & 0xffffffff, h[2] & 0xffffffff
+        seg = self.pairs[4:4 + 2 * reg_a].view(-1, 2)
+        over = self.pairs[4 + 2 * reg_a:4 + 2 * (reg_a + min(n_over, self.pair_cap - reg_a))].view(-1, 2)
+        return torch.cat([seg[seg[:, 0] != -1], over]).long()
 
 
 def _emb3(E, name):
