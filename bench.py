@@ -229,7 +229,7 @@ def main():
                 graphs = []
                 for gi in range(2):
                     gph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gph):
+                    with torch.cuda.graph(gph, capture_error_mode='thread_local'):
                         res = evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, metrics_out=pins[gi])
                     gph.replay()
                     torch.cuda.synchronize()

@@ -87,12 +87,9 @@ class HipBackend:
         self._unpacked = side
 
     def _emit_packed(self, on):
-        fused = self.precision in ('fp16', 'bf16')
         skip = {'txt': [self.txt_layer()], 'vis': [self.vis_layer()]}.get(getattr(self, '_unpacked', None), [])
         for layer in self._attention_layers():
-            layer.emit_packed = self.precision if (on and fused and hasattr(layer, 'fuse_planes') and
-                                                   type(layer).__name__ != 'JustAverage' and
-                                                   not any(layer is x for x in skip)) else None
+            layer.emit_packed = self.precision if (on and self._fused_pack(layer) and not any(layer is x for x in skip)) else None
 
     def pack(self, E, layer=None):
         """GEMM operand of an embedding matrix: taken from the fuse launch when it emitted one, else a pack_rows pass."""
@@ -102,9 +99,14 @@ class HipBackend:
             return p
         return ops.pack_rows(E, True, 1e-13, self.precision)
 
-    def pack_gathered(self, E):
-        """GEMM operand of gathered fp32 embedding rows (N, H, d)."""
-        return ops.pack_rows(E, True, 1e-13, self.precision)
+    def _fused_pack(self, layer):
+        return (self.precision in ('fp16', 'bf16') and layer is not None and hasattr(layer, 'fuse_planes') and
+                type(layer).__name__ != 'JustAverage')
+
+    def pack_gathered(self, E, layer=None):
+        """GEMM operand of gathered fp32 embedding rows (N, H, d): bit-for-bit what pack() hands over on a single rank -- the fuse
+        launch converts its unit-norm rows without re-normalising, pack_rows re-normalises (loss.cosine_sim, loss.py:30-34)."""
+        return ops.pack_rows(E, not self._fused_pack(layer), 1e-13, self.precision)
 
     def sim(self, T, V, heads):
         return ops.sim_gemm(T, V, heads=heads)
@@ -149,7 +151,9 @@ class GraphRunner:
     def __call__(self, name, fn):
         if name not in self.graphs:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread-local capture mode: the process group's watchdog thread keeps polling its events (hipEventQuery) while this
+            # thread captures; under the default global mode that query is an illegal call and aborts the process
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 out = fn()
             self.graphs[name], self.outs[name] = g, out
         self.graphs[name].replay()
@@ -256,7 +260,7 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
         def prep_phase():
             if comm:
                 Et = _compact(gathered, sizes, nmax, heads)
-                T = compute.pack_gathered(Et)
+                T = compute.pack_gathered(Et, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack_gathered(Et)
             elif hasattr(compute, 'embed_both'):
                 Et, T = Et_all, T_all
             else:
@@ -343,7 +347,7 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
         def rank_phase():
             if comm:
                 Ev = _compact(gathered, vsizes, vmax, heads)
-                V = compute.pack_gathered(Ev)
+                V = compute.pack_gathered(Ev, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack_gathered(Ev)
             else:
                 Ev, V = vis_emb, V_local
             st = compute.prepare(txt_emb, Ev, T_local, V, gt_local, 0)

@@ -38,3 +38,27 @@ def oracle_towers(model, vis_np, txt_np, rows_t=None):
     ve = O.fuse_tower(vspecs, O.attention_from_sd(sd, 'vis_net.attention_layer.', H, False, False), H)
     te = O.fuse_tower(tspecs, O.attention_from_sd(sd, 'txt_net.attention_layer.', H, False, False), H)
     return ve, te
+
+
+def oracle_towers_framelaff(model, frames_np, txt_np, rows_t=None):
+    """Embeddings of the synthetic 'FrameLAFF' towers (laff_amd.synth.build_model(frames=F): every video feature is a frame
+    tensor, Attention_1(with_ave=False, mul=False) over the zero-padded frames -> (B, 512) -> FC -> tanh -> BN -> LAFF) from the
+    oracle.  frames_np: {name: (B, Fmax, 512), 'mask_tensor': ...}."""
+    from oracle import laff_oracle as O
+    opt = model.vis_net.opt
+    H = opt.multi_head_attention['heads']
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    vspecs = []
+    for n in opt.vid_frame_feats:
+        pre = 'vis_net.frame_attention.%s.0.' % n
+        vec = O.frame_attention(frames_np[n], sd[pre + 'embedding_common.0.weight'].reshape(-1), sd[pre + 'embedding_common.0.bias'].reshape(()),
+                                False, False, sd[pre + 'global_emb_weight_net.weight'].reshape(()))
+        vspecs.append(O.feature_spec(sd, 'vis_net.%s.' % n, vec, 'tanh', H, n in opt.vis_no_transform))
+    tspecs = []
+    for e in model.txt_net.encoder_name_list:
+        x = txt_np[ENC_KEY[e]]
+        tspecs.append(O.feature_spec(sd, 'txt_net.transform_layer.%s_transform.' % e, x if rows_t is None else x[rows_t],
+                                     'tanh', H, e in opt.txt_no_transform))
+    ve = O.fuse_tower(vspecs, O.attention_from_sd(sd, 'vis_net.vis_attention_layer.', H, False, False), H)
+    te = O.fuse_tower(tspecs, O.attention_from_sd(sd, 'txt_net.attention_layer.', H, False, False), H)
+    return ve, te
