@@ -131,10 +131,44 @@ def cpu_baseline(workload, sample_nt, sample_nv, heads, d, seed, spec=None):
         cores = max([int(p.get('num_threads', 1)) for p in threadpool_info()] or [1])
     except Exception:  # noqa: BLE001
         cores = os.cpu_count()
-    return {'value': sample_nt * sample_nv / dt, 'unit': 'pairs/s', 'cores': cores, 'host_cores': os.cpu_count(), 'kind': 'port',
+    main = {'value': sample_nt * sample_nv / dt, 'unit': 'pairs/s', 'cores': cores, 'host_cores': os.cpu_count(), 'kind': 'port',
             'sample': '%dx%d slice of the same synthetic workload (seed, generator, weights), numpy oracle in the reference\'s '
-                      'batch-64 block-loop shape, %.1f s on the GPU box host' % (sample_nt, sample_nv, dt),
+                      'batch-64 block-loop shape (towers + per-block cosine), ranks by counting, %.1f s on the GPU box host'
+                      % (sample_nt, sample_nv, dt),
             'r1': metrics[0]}
+    # BASELINE.md section 3 variants.  (a) reference-shaped INCLUDING its ranking stage: full-matrix argsort + the per-query label loop
+    # + evaluation.eval on the label matrix (predictor.py:232-246), on a row sample (the label matrix alone is 8 B per pair);
+    # the score stage is charged pro rata.  (b) vectorised upper bound: whole-matrix towers, ONE GEMM, ranks by counting.
+    variants = []
+    try:
+        na = min(sample_nt, 4000)
+        t1 = time.perf_counter()
+        inds = np.argsort(S[:na], axis=1)
+        label = np.zeros((na, sample_nv))
+        for i in range(na):
+            ind = inds[i][::-1]
+            label[i][np.where(ind == gt_np[i])[0]] = 1
+        m_a = O.eval_label_matrix(label)
+        dt_a = time.perf_counter() - t1 + dt * na / sample_nt
+        variants.append({'kind': 'port-blockloop-argsort', 'value': na * sample_nv / dt_a, 'unit': 'pairs/s', 'cores': cores,
+                         'sample': 'first %d texts x %d videos: block-loop scores (pro rata) + np.argsort + per-query label loop + '
+                                   'eval on the label matrix, %.1f s' % (na, sample_nv, dt_a), 'r1': m_a[0]})
+        del inds, label
+        t2 = time.perf_counter()
+        specs_v = [O.feature_spec(sd, 'vis_net.VisMutiTransformNet.%s.' % n, vis_np[n], 'tanh', heads, n in vnt) for n in vid_names]
+        specs_t = [O.feature_spec(sd, 'txt_net.transform_layer.%s_transform.' % e, txt_np[enc[e]], 'tanh', heads, e in tnt) for e in names]
+        ve_all, te_all = O.fuse_tower(specs_v, att_v, heads), O.fuse_tower(specs_t, att_t, heads)
+        S2 = O.txt2vis_matrix_fast(te_all, ve_all)
+        r2 = (S2 > S2[np.arange(sample_nt), gt_np][:, None]).sum(axis=1) + 1
+        m_b = O.eval_from_positions([[r] for r in r2])
+        dt_b = time.perf_counter() - t2
+        variants.append({'kind': 'port-vectorised', 'value': sample_nt * sample_nv / dt_b, 'unit': 'pairs/s', 'cores': cores,
+                         'sample': '%dx%d: whole-matrix towers, one GEMM over concatenated heads, ranks by counting, %.1f s'
+                                   % (sample_nt, sample_nv, dt_b), 'r1': m_b[0]})
+    except Exception as e:  # noqa: BLE001
+        variants.append({'kind': 'error', 'sample': str(e)})
+    main['variants'] = variants
+    return main
 
 
 def main():
@@ -147,9 +181,12 @@ def main():
     ap.add_argument('--fc-precision', default='fp16x3', help="FC projections: fp32 (fp32 MFMA) | fp16x3 (exact fp16 hi/lo split)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of HIP-graph replays')
-    ap.add_argument('--shard', default='video', choices=['video', 'text'],
-                    help="N > 1 decomposition: 'video' (BASELINE.json: video-row shards, all-gather of the text operand) or 'text' "
-                         "(text-row shards, all-gather of the smaller video operand, no all-reduce)")
+    ap.add_argument('--shard', default='auto', choices=['auto', 'video', 'text'],
+                    help="N > 1 decomposition: 'video' (BASELINE.json: video-row shards, all-gather of the text embeddings, two small "
+                         "all-reduces), 'text' (text-row shards, all-gather of the video embeddings, no all-reduce) or 'auto' = the one "
+                         "that gathers fewer rows (laff_amd.dist.choose_sharding)")
+    ap.add_argument('--no-extra-modes', action='store_true', help='skip the sustained loop and the count-only mode (profiling runs)')
+    ap.add_argument('--sustain-seconds', type=float, default=2.0, help='extra untimed-by-the-driver loop reporting the sustained rate')
     ap.add_argument('--force-dist', action='store_true', help='run the N > 1 code path (collectives included) on a 1-rank group')
     ap.add_argument('--profile-steps', type=int, default=5, help='eager steps (after the timed region) for per-kernel events')
     ap.add_argument('--seed', type=int, default=1237)
@@ -158,20 +195,31 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 or ('RANK' in os.environ and '--force-dist' in sys.argv):
+    if world > 1 or ('RANK' in os.environ and args.force_dist):
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    elif args.force_dist:
+        # no launcher environment: a 1-rank RCCL group of our own, so that --force-dist really runs the collectives
+        import socket
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, world_size=1, rank=0,
+                                device_id=torch.device('cuda', local_rank))
     if args.gpus != world:
         if rank == 0:
             print('warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
     dev = torch.device('cuda', local_rank)
 
     from laff_amd import synth
-    from laff_amd.dist import HipBackend, evaluate_sharded, evaluate_sharded_by_text, shard_bounds
+    from laff_amd.dist import HipBackend, check_metrics_flag, choose_sharding, evaluate_sharded, evaluate_sharded_by_text, shard_bounds
     import laff_amd.model.model as M
     M.FC_PRECISION = args.fc_precision
     Nt, Nv, heads, d, frames = synth.WORKLOADS[args.workload]
     spec = synth.SPECS.get(args.workload)
+    shard = choose_sharding(Nt, Nv) if args.shard == 'auto' else args.shard
     model = synth.build_model(heads, d, dev, frames=frames, seed=args.seed, spec=spec)
     vis, txt, gt, lens = synth.make_features(Nt, Nv, dev, frames=frames, seed=args.seed, spec=spec)
     t0, t1 = shard_bounds(Nt, world, rank)
@@ -187,22 +235,37 @@ def main():
     ops.profiler = prof
 
     metrics_pinned = torch.zeros(8, dtype=torch.float64).pin_memory()
-    force_dist = args.force_dist and dist.is_initialized()
+    force_dist = args.force_dist
+    if force_dist and not dist.is_initialized():
+        raise SystemExit('--force-dist: no process group could be initialised')
     distributed = world > 1 or force_dist
 
     pins = [metrics_pinned, torch.zeros(8, dtype=torch.float64).pin_memory()]
 
-    def step(timed, async_metrics=False, runner=None, state=None, slot=0):
+    def step(timed, async_metrics=False, runner=None, state=None, slot=0, want_scores=True):
         timer.enabled = timed
         prof.enabled = timed
         timer.start()
-        if args.shard == 'text' and distributed:
-            return evaluate_sharded_by_text(backend, vis_l, txt_l, gt, Nt, Nv, heads,
+        if shard == 'text' and distributed:
+            return evaluate_sharded_by_text(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer, want_scores=want_scores,
                                             metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
                                             force_collectives=force_dist, finish_tag=str(slot))
-        return evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer,
+        return evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer, want_scores=want_scores,
                                 metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
                                 force_collectives=force_dist, finish_tag=str(slot))
+
+    def sclk_sampler(stop, out):
+        # shader clock actually held during a loop (the chip clocks to its power budget: MI355X_MICROARCH.md "DVFS give-back")
+        import re
+        import subprocess
+        while not stop.is_set():
+            try:
+                txt_ = subprocess.run(['rocm-smi', '--showclocks'], capture_output=True, text=True, timeout=5).stdout
+                m = re.findall(r'sclk clock level:? *\d*:? *\((\d+)Mhz\)', txt_)
+                if m:
+                    out.append(int(m[local_rank if local_rank < len(m) else 0]))
+            except Exception:  # noqa: BLE001
+                return
 
     # Launch modes of the timed region (host issue of ~15 launches costs 0.3-0.4 ms per step, as much as the GPU work of a
     # 1/4 shard, and sits on the critical path because every step ends with a host sync on the 7 metrics):
@@ -271,8 +334,10 @@ def main():
             events[k % 2].record()
             if k:
                 events[(k - 1) % 2].synchronize()
+                check_metrics_flag(pins[(k - 1) % 2])
                 seen.append(float(pins[(k - 1) % 2][0]))
         events[(args.steps - 1) % 2].synchronize()
+        check_metrics_flag(pins[(args.steps - 1) % 2])
         seen.append(float(pins[(args.steps - 1) % 2][0]))
         assert len(seen) == args.steps
     else:
@@ -300,6 +365,61 @@ def main():
     else:
         final_metrics = res['metrics']
         prof_steps = args.steps
+
+    sustained, no_scores = None, None
+    if graph is not None and world == 1 and not distributed and not args.no_extra_modes:
+        # (i) sustained rate: the driver's timed region is tens of milliseconds -- a burst; this loop runs >= --sustain-seconds
+        if args.sustain_seconds > 0:
+            import threading
+            stop, clocks = threading.Event(), []
+            th = threading.Thread(target=sclk_sampler, args=(stop, clocks), daemon=True)
+            th.start()
+            torch.cuda.synchronize()
+            ts, n_s = time.perf_counter(), 0
+            while time.perf_counter() - ts < args.sustain_seconds:
+                for k in range(50):
+                    graphs[k % 2].replay()
+                torch.cuda.current_stream().synchronize()
+                n_s += 50
+            dt_s = time.perf_counter() - ts
+            stop.set()
+            th.join(timeout=6)
+            sustained = {'seconds': round(dt_s, 2), 'steps': n_s, 'ms_per_step': round(1e3 * dt_s / n_s, 4),
+                         'value': float(Nt) * Nv * n_s / dt_s, 'sclk_mhz_samples': clocks[:8]}
+        # (ii) the count-only mode (ranks + metrics, S never written): what the similarity GEMM does when the caller does not ask for
+        # the score matrix (with K = 512 the fp32 S store is the HBM-bound part; without it the GEMM is MFMA-bound)
+        g2 = []
+        prof.enabled = timer.enabled = False          # no events inside a capture
+        for gi in range(2):
+            gph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gph, capture_error_mode='thread_local'):
+                evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, metrics_out=pins[gi], want_scores=False)
+            gph.replay()
+            torch.cuda.synchronize()
+            g2.append(gph)
+        tn = time.perf_counter()
+        for k in range(args.steps):
+            g2[k % 2].replay()
+        torch.cuda.synchronize()
+        dt_n = time.perf_counter() - tn
+        check_metrics_flag(pins[0]); check_metrics_flag(pins[1])
+        m_ns = tuple(pins[(args.steps - 1) % 2][:7].tolist())
+        prof.spans, keep_spans = [], prof.spans
+        for _ in range(args.profile_steps):
+            step(True, want_scores=False)
+        torch.cuda.synchronize()
+        sim_ns = prof.totals().get('sim_gemm', (0.0, 1))
+        sim_ns_ms = sim_ns[0] / max(1, sim_ns[1])
+        prof.spans = keep_spans
+        Kk = heads * d
+        fl = 2.0 * Kk * float(Nt) * Nv * (3 if args.precision.endswith('x3') else 1)
+        no_scores = {'ms_per_step': round(1e3 * dt_n / args.steps, 4), 'value': float(Nt) * Nv * args.steps / dt_n,
+                     'metrics_equal_to_headline_mode': m_ns == tuple(final_metrics),
+                     'roofline': {'kernel': 'laff_sim_gemm_banded (S == NULL)', 'bound': 'mfma', 'avg_launch_ms': round(sim_ns_ms, 5),
+                                  'achieved': round(fl / (sim_ns_ms * 1e-3) / 1e12, 2) if sim_ns_ms > 0 else None,
+                                  'peak': MFMA_PEAK_TFLOPS['f16'], 'unit': 'TFLOP/s',
+                                  'frac': round(fl / (sim_ns_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS['f16'], 4) if sim_ns_ms > 0 else None}}
+        del g2
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -335,7 +455,7 @@ def main():
             # embeddings (fp32) + operands (16-bit) of every row once, + the ground-truth video row of every text (at most nvl distinct)
             'rank_prepare': ('hbm', (4.0 + 2.0 * (2 if x3 == 3 else 1)) * K * (Nt + nvl) + 4.0 * K * min(Nt, nvl), HBM_PEAK_GBS, 1e9, 'GB/s'),
         }
-        sim_r, sim_c = (ntl, Nv) if (args.shard == 'text' and distributed) else (Nt, nvl)
+        sim_r, sim_c = (ntl, Nv) if (shard == 'text' and distributed) else (Nt, nvl)
         sim_bytes = 4.0 * sim_r * sim_c + 2.0 * (sim_r + sim_c) * K              # fp32 S written once + 16-bit operands read once
         sim_flops = 2.0 * K * sim_r * sim_c * x3
         sim_ms = launches.get('sim_gemm', (0.0, 0))[0]
@@ -360,19 +480,27 @@ def main():
             roof = {'kernel': 'laff_' + dom, 'bound': pk['bound'], 'achieved': pk['achieved'], 'peak': pk['peak'], 'unit': pk['unit'],
                     'frac': pk['frac'], 'traffic': None, 'launches_per_step': pk['launches_per_step'],
                     'avg_launch_ms': round(pk['ms_per_step'] / max(1, pk['launches_per_step']), 5)}
-        # measured HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command, committed under profiles/
+        # measured HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command (tools/profile_round.sh), committed
+        # under profiles/ and keyed to the kernel sources they were measured on -- a stale file is refused, not quoted
         try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')))
-            if (tj.get('workload') == args.workload and tj.get('precision') == args.precision and
-                    tj.get('fc_precision') == args.fc_precision and dom in tj['kernels'] and world == 1):
-                k = tj['kernels'][dom]
-                roof['traffic'] = round((k['fetch_corrected_MB'] + k['write_MB']) * 1e6)
-                alg = sim_bytes if dom == 'sim_gemm' else (work[dom][1] if work.get(dom, ('', 0))[0] == 'hbm' else None)
-                roof['traffic_note'] = ('bytes per launch: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), rocprofv3 --pmc passes '
-                                        'of this command (tools/profile_round.sh), profiles/r1_bench_pmc_*.txt'
-                                        + ('; algorithmic %.0f MB' % (alg / 1e6) if alg else ''))
-        except Exception:  # noqa: BLE001
-            pass
+            import glob
+            from laff_amd.build import source_hash
+            sha = source_hash()
+            for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+                tj = json.load(open(f))
+                if (tj.get('src_sha') == sha and tj.get('workload') == args.workload and tj.get('precision') == args.precision and
+                        tj.get('fc_precision') == args.fc_precision and dom in tj['kernels'] and world == 1):
+                    k = tj['kernels'][dom]
+                    roof['traffic'] = round((k['fetch_corrected_MB'] + k['write_MB']) * 1e6)
+                    alg = sim_bytes if dom == 'sim_gemm' else (work[dom][1] if work.get(dom, ('', 0))[0] == 'hbm' else None)
+                    roof['traffic_note'] = ('bytes per launch: WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), rocprofv3 --pmc passes of '
+                                            'this command on these kernel sources (src_sha %s), %s' % (sha, os.path.basename(f))
+                                            + ('; algorithmic %.0f MB' % (alg / 1e6) if alg else ''))
+                    break
+            else:
+                roof['traffic_note'] = 'no PMC measurement under profiles/ matches the current kernel sources (src_sha %s)' % sha
+        except Exception as e:  # noqa: BLE001
+            roof['traffic_note'] = 'traffic lookup failed: %s' % e
         m = res['metrics']
         agreement = None
         if world == 1 and not args.no_cpu_baseline:
@@ -414,13 +542,19 @@ def main():
                            'video %s (no FC: %s) + text %s (no FC: %s, bow sparse CSR)' % (spec['vid'], spec['vis_no_transform'],
                                                                                          spec['txt'], spec['txt_no_transform']),
                            heads, d),
-                       'parallelism': (('video-row shards x%d, all-gather of text operand' if args.shard == 'video' else
-                                        'text-row shards x%d, all-gather of video operand + ranks') % world) if world > 1 else 'single GPU',
-                       'scores': 'fp32 S materialised in HBM',
+                       'parallelism': (('video-row shards x%d, all-gather of the fp32 text embeddings, all-reduce MAX(s_gt) + SUM(counts)'
+                                        if shard == 'video' else
+                                        'text-row shards x%d, all-gather of the fp32 video embeddings + of the ranks') % world)
+                       if distributed else 'single GPU',
+                       'force_dist': bool(force_dist), 'shard': shard if distributed else None,
+                       'scores': 'fp32 S materialised in HBM (count-only mode reported under no_scores_mode)',
+                       'ranks': 'exact: error-band count in the GEMM epilogue + fp64 re-score of the in-band pairs',
                        'launch': launch_mode},
             'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6],
                         'vs_strict_similarity': agreement},
-            'stages_ms': {k: round(v, 4) for k, v in stages.items()},
+            'stages_ms_eager_pass': {k: round(v, 4) for k, v in stages.items()},   # host-issued launches with events: longer than a graph step
+            'sustained': sustained,
+            'no_scores_mode': no_scores,
             'kernels': per_kernel,
             'roofline': roof,
         }

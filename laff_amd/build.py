@@ -33,6 +33,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """sha256 over the kernel sources + headers: what a measured artefact (profiles/*_traffic.json) is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def build_library(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     cc = hipcc()

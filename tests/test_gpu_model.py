@@ -244,3 +244,10 @@ def test_bench_line_contract():
         assert k in line['roofline'], k
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in line['cpu_baseline'], k
+    # round 2: exact ranks reported against float64 scores, the count-only mode, the sustained loop, the CPU variants
+    q = line['quality']['vs_strict_similarity']
+    assert q['identical_ranks_frac'] == 1.0 and q['identical_ranks_frac_vs_fp64_scores'] == 1.0 and q['pair_list_overflow'] is False
+    assert line['no_scores_mode']['metrics_equal_to_headline_mode'] is True and line['no_scores_mode']['roofline']['bound'] == 'mfma'
+    assert line['sustained']['seconds'] >= 1.9
+    assert {v['kind'] for v in line['cpu_baseline']['variants']} == {'port-blockloop-argsort', 'port-vectorised'}
+    assert abs(line['cpu_baseline']['r1'] - line['quality']['R@1']) < 1e-9

@@ -11,10 +11,14 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from laff_amd.build import source_hash  # noqa: E402
+
 ENTRY = [('gemm_nt_x3_fused_grouped_kernel', 'fc_act_bn'), ('gemm_nt_x3_grouped_kernel', 'fc_act_bn'), ('gemm_nt_grouped_kernel', 'fc_act_bn'), ('gemm_nt_x3_kernel', 'sim_gemm'),
          ('gemm_nt_kernel', 'sim_gemm'), ('split_rows_kernel', 'split_rows'), ('fuse_reg_kernel', 'fuse'), ('fuse_stream_kernel', 'fuse'),
          ('frame_fuse_kernel', 'frame_fuse'), ('row_dot_gt_kernel', 'row_dot_gt'), ('fc_gather_kernel', 'fc_gather'),
-         ('rank_metrics_kernel', 'rank_metrics'), ('pack_rows_kernel', 'pack_rows')]
+         ('rank_metrics_kernel', 'rank_metrics'), ('pack_rows_kernel', 'pack_rows'), ('rank_prepare_kernel', 'rank_prepare'),
+         ('rank_resolve_kernel', 'rank_resolve'), ('split_rows_kernel', 'row_scales')]
 
 
 def collect(d, counter):
@@ -39,9 +43,9 @@ def main():
         kernels[k] = {'launches_seen': len(fetch[k]), 'fetch_reported_MB': round(f / 1e6, 1), 'fetch_corrected_MB': round(2 * f / 1e6, 1),
                       'write_MB': round(w / 1e6, 1)}
     json.dump({'_comment': 'average bytes per launch over every launch of the kernel in `python3 bench.py --steps 5 --warmup 2 '
-                           '--no-cpu-baseline` (warm-up, graph replays and the eager profiling pass alike); FETCH_SIZE x2 per '
+                           '--no-cpu-baseline --no-extra-modes` (warm-up, graph replays and the eager profiling pass alike); FETCH_SIZE x2 per '
                            'MI355X_MICROARCH.md; made by tools/make_traffic.py from separate --pmc passes',
-               'workload': 'c4_40kx10k', 'precision': 'fp16', 'fc_precision': 'fp16x3', 'kernels': kernels},
+               'workload': 'c4_40kx10k', 'precision': 'fp16', 'fc_precision': 'fp16x3', 'src_sha': source_hash(), 'kernels': kernels},
               open(sys.argv[3], 'w'), indent=1)
     print(json.dumps(kernels, indent=1))
 

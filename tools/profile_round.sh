@@ -5,11 +5,11 @@
 #   3. the un-profiled bench line                                     -> profiles/<tag>_bench_line.json
 # Counter passes never combine --pmc with a trace domain (MI355X_MICROARCH.md; the pool refuses that combination).
 set -e
-TAG=${1:-r1}
+TAG=${1:-r2}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-modes"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- $BENCH > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- $BENCH > "$OUT/fetch.log" 2>&1
