@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 10
+#define LAFF_ABI_VERSION 11
 
 enum {
     LAFF_OK = 0,
@@ -167,7 +167,17 @@ typedef struct {
     const float* wt;      /* [dk, ldwt] = W^T */
     int ldwt, dk;
     const float* bias;    /* [H*d] or NULL */
+    /* optional per-row factor [N] applied after the affine: the inverse row norm of `local_embs = l2norm(local_embs, dim=2)` in the
+     * expert-embedding branch (model/model.py:1866-1873, :1686-1694), produced by laff_plane_row_norms; NULL = none.  Not with gather
+     * planes. */
+    const float* row_scale;
 } laff_plane;
+
+/* out[l * N + n] = 1 / (|x_l[n, :]|_2 + 1e-13 + 1e-14) over all H*d columns of plane l as laff_fuse would read it (activation,
+ * tiling, affine -- the expert embedding row rides in `shift`): what `l2norm(local_embs, dim=2)` divides by (loss.py:8-13).
+ * The planes' own row_scale must be NULL here.  flags: only LAFF_ATT_NO_SPLIT_HEAD matters (d = D columns, one "head"). */
+int laff_plane_row_norms(laff_ctx* ctx, const laff_plane* planes /*host array of L*/, int L, int N, int H, int d, unsigned flags,
+                         float* out /*[L, N]*/);
 
 /* E[N,H,d] (unit L2 norm per (n,h) unless JUST_AVERAGE).  w [H,d], b [H], gw [H] device arrays.
  * attn_w: optional [N,H,L] softmax weights (the `self.weights` side output, Attention.py:90).

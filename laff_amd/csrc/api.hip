@@ -392,32 +392,23 @@ int laff_fuse(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int 
     return laff_fuse_packed(ctx, planes, L, N, H, d, w, b, gw, flags, E, attn_w, nullptr, LAFF_PREC_FP16, 1.0f);
 }
 
-int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
-                     const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale) {
-    CHECK_CTX(ctx);
-    if (N == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
-    if (E16 && precision != LAFF_PREC_FP16 && precision != LAFF_PREC_BF16)
-        return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed: E16 is a single-plane operand (FP16 or BF16), got precision %d", precision);
-    if (E16 && !aligned16(E16)) return fail(LAFF_E_ALIGN, "laff_fuse_packed: E16 must be 16-byte aligned");
-    if (E16 && (flags & LAFF_ATT_JUST_AVERAGE)) return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed: JUST_AVERAGE output is not unit-norm");
-    if (!planes || !E) return fail(LAFF_E_ARG, "laff_fuse: null planes/E");
+// plane descriptors -> FuseArgs (shared by laff_fuse* and laff_plane_row_norms)
+static int parse_planes(const laff_plane* planes, int L, int N, int H, int d, unsigned flags, laff::FuseArgs& a, bool& any_gather) {
+    if (!planes) return fail(LAFF_E_ARG, "laff_fuse: null planes");
     if (L < 1 || L > laff::MAX_L) return fail(LAFF_E_SHAPE, "laff_fuse: L=%d outside [1,%d]", L, laff::MAX_L);
     if (N < 0 || H < 1 || d < 4 || (d & 3)) return fail(LAFF_E_SHAPE, "laff_fuse: need N>=0, H>=1, d%%4==0 (N=%d H=%d d=%d)", N, H, d);
-    const bool javg = flags & LAFF_ATT_JUST_AVERAGE;
-    if (!javg && (!w || !b)) return fail(LAFF_E_ARG, "laff_fuse: null w/b");
-    if ((flags & LAFF_ATT_WITH_AVE) && !gw) return fail(LAFF_E_ARG, "laff_fuse: WITH_AVE needs gw");
-    if (!aligned16(E) || (w && !aligned16(w))) return fail(LAFF_E_ALIGN, "laff_fuse: E/w must be 16-byte aligned");
     const bool nosplit = flags & LAFF_ATT_NO_SPLIT_HEAD;
-    laff::FuseArgs a{};
-    bool any_gather = false;
+    any_gather = false;
     for (int l = 0; l < L; ++l) {
         const laff_plane& p = planes[l];
         if ((p.scale == nullptr) != (p.shift == nullptr)) return fail(LAFF_E_ARG, "laff_fuse: plane %d scale/shift must come together", l);
         if (p.act < LAFF_ACT_NONE || p.act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fuse: plane %d bad act %d", l, p.act);
         if (p.scale && (!aligned16(p.scale) || !aligned16(p.shift))) return fail(LAFF_E_ALIGN, "laff_fuse: plane %d affine not 16-byte aligned", l);
+        a.rownorm[l] = p.row_scale;
         if (!p.src && p.wt) {                          // gather plane
             if (!p.indptr || !p.indices) return fail(LAFF_E_ARG, "laff_fuse: gather plane %d needs indptr / indices", l);
             if (p.tile || nosplit || d > 512) return fail(LAFF_E_UNSUPPORTED, "laff_fuse: gather plane %d needs split heads of d <= 512, not tiled", l);
+            if (p.row_scale) return fail(LAFF_E_UNSUPPORTED, "laff_fuse: gather plane %d cannot take a row_scale (project the feature with laff_fc_gather_act_bn first)", l);
             if (p.dk < 1 || p.ldwt < H * d || (p.ldwt & 3)) return fail(LAFF_E_SHAPE, "laff_fuse: gather plane %d: dk=%d ldwt=%d (need >= %d, multiple of 4)", l, p.dk, p.ldwt, H * d);
             if (!aligned16(p.wt) || (p.bias && !aligned16(p.bias))) return fail(LAFF_E_ALIGN, "laff_fuse: gather plane %d not 16-byte aligned", l);
             a.g_indptr[l] = p.indptr; a.g_indices[l] = p.indices; a.g_values[l] = p.values; a.g_wt[l] = p.wt; a.g_bias[l] = p.bias;
@@ -433,13 +424,47 @@ int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int 
         if (!aligned16(p.src)) return fail(LAFF_E_ALIGN, "laff_fuse: plane %d not 16-byte aligned", l);
         a.src[l] = p.src; a.ld[l] = p.ld; a.tile[l] = p.tile; a.scale[l] = p.scale; a.shift[l] = p.shift; a.act[l] = p.act;
     }
-    a.head_major = any_gather ? 1 : 0;
-    if (N == 0) return LAFF_OK;
     a.L = L; a.N = N; a.H = H; a.d = d; a.head_stride = nosplit ? 0 : d;
-    a.w = w; a.b = b; a.gw = gw; a.flags = flags; a.E = E; a.attn_w = attn_w;
+    a.flags = flags;
+    return LAFF_OK;
+}
+
+int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
+                     const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale) {
+    CHECK_CTX(ctx);
+    if (N == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
+    if (E16 && precision != LAFF_PREC_FP16 && precision != LAFF_PREC_BF16)
+        return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed: E16 is a single-plane operand (FP16 or BF16), got precision %d", precision);
+    if (E16 && !aligned16(E16)) return fail(LAFF_E_ALIGN, "laff_fuse_packed: E16 must be 16-byte aligned");
+    if (E16 && (flags & LAFF_ATT_JUST_AVERAGE)) return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed: JUST_AVERAGE output is not unit-norm");
+    if (!planes || !E) return fail(LAFF_E_ARG, "laff_fuse: null planes/E");
+    const bool javg = flags & LAFF_ATT_JUST_AVERAGE;
+    if (!javg && (!w || !b)) return fail(LAFF_E_ARG, "laff_fuse: null w/b");
+    if ((flags & LAFF_ATT_WITH_AVE) && !gw) return fail(LAFF_E_ARG, "laff_fuse: WITH_AVE needs gw");
+    if (!aligned16(E) || (w && !aligned16(w))) return fail(LAFF_E_ALIGN, "laff_fuse: E/w must be 16-byte aligned");
+    laff::FuseArgs a{};
+    bool any_gather = false;
+    if (int rc = parse_planes(planes, L, N, H, d, flags, a, any_gather)) return rc;
+    a.head_major = any_gather ? 1 : 0;
+    a.w = w; a.b = b; a.gw = gw; a.E = E; a.attn_w = attn_w;
     a.E16 = E16; a.e16_bf16 = precision == LAFF_PREC_BF16; a.e16_scale = prescale;
     DeviceGuard g(ctx->device);
     HIP_TRY(laff::launch_fuse(a, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_plane_row_norms(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, unsigned flags, float* out) {
+    CHECK_CTX(ctx);
+    if (N == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
+    if (!out) return fail(LAFF_E_ARG, "laff_plane_row_norms: null out");
+    laff::FuseArgs a{};
+    bool any_gather = false;
+    if (int rc = parse_planes(planes, L, N, H, d, flags, a, any_gather)) return rc;
+    if (any_gather) return fail(LAFF_E_UNSUPPORTED, "laff_plane_row_norms: gather planes are not supported (project the feature first)");
+    for (int l = 0; l < L; ++l)
+        if (a.rownorm[l]) return fail(LAFF_E_ARG, "laff_plane_row_norms: plane %d already carries a row_scale", l);
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_plane_row_norms(a, out, ctx->stream));
     return LAFF_OK;
 }
 

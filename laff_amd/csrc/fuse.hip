@@ -62,7 +62,34 @@ __device__ __forceinline__ float4 load_plane(const FuseArgs& a, int l, long n, i
         const float4 t = *(const float4*)(a.shift[l] + ai);
         v = make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
     }
+    if (a.rownorm[l]) v = scl4(v, a.rownorm[l][n]);             // wave-uniform; l2norm(local_embs, dim=2) of the expert branch
     return v;
+}
+
+// out[l][n] = 1 / (|x_l[n, :]|_2 + 1e-13 + 1e-14) over ALL columns of the stacked plane (every head): the factor that
+// `local_embs = l2norm(local_embs, dim=2)` applies after the expert embedding was added (model/model.py:1866-1873, :1686-1694;
+// loss.l2norm, loss.py:8-13).  One wavefront per (row, plane).
+__global__ __launch_bounds__(256) void plane_row_norms_kernel(FuseArgs a, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)a.N * a.L) return;
+    const long n = item / a.L;
+    const int l = (int)(item - n * a.L);
+    const int nh = a.head_stride ? a.H : 1;                      // without split heads the stacked row has d columns
+    float ss = 0.f;
+    for (int h = 0; h < nh; ++h)
+        for (int col = lane * 4; col < a.d; col += 256) {
+            const float4 v = load_plane(a, l, n, h, col);
+            ss += dot4(v, v);
+        }
+    ss = wave_sum(ss);
+    if (lane == 0) out[(long)l * a.N + n] = 1.0f / (sqrtf(ss) + 1e-13f + 1e-14f);
+}
+
+hipError_t launch_plane_row_norms(const FuseArgs& a, float* out, hipStream_t st) {
+    const long items = (long)a.N * a.L;
+    hipLaunchKernelGGL(plane_row_norms_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a, out);
+    return hipGetLastError();
 }
 
 // gather plane (sparse feature through its FC, fc_gather_kernel's arithmetic inside the fuse launch): the projected plane is

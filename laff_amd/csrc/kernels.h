@@ -66,6 +66,7 @@ struct FuseArgs {
     int ld[MAX_L];
     int tile[MAX_L];
     int act[MAX_L];       // LAFF_ACT_* applied to the plane before its affine
+    const float* rownorm[MAX_L];      // optional per-row factor [N] applied after the affine (expert-embedding l2norm branch)
     // gather planes (src == null): plane value = sum_j values_j * Wt[indices_j, column] + bias[column]  (sparse bag-of-words FC)
     const int* g_indptr[MAX_L];
     const int* g_indices[MAX_L];
@@ -87,6 +88,7 @@ struct FuseArgs {
     float e16_scale;
 };
 hipError_t launch_fuse(const FuseArgs& a, hipStream_t st);
+hipError_t launch_plane_row_norms(const FuseArgs& a, float* out /*[L][N]*/, hipStream_t st);
 
 struct FrameArgs {
     const float* frames;  // [B, Fmax, d]

@@ -23,14 +23,20 @@ def _planes_of(local_embs):
     return [(local_embs[:, l, :], False, None, None) for l in range(local_embs.shape[1])]
 
 
+def _full_width(plane, heads, D):
+    """a tiled plane (src (N, D / heads), tile, scale, shift) written out as (N, D): repeat over heads + the folded affine"""
+    out = ops.fuse([plane], heads, D // heads, None, None, None, ops.attention_flags(just_average=True))
+    return out.view(out.shape[0], D)
+
+
 class JustAverage(nn.Module):
     def forward(self, local_embs, raw_global_emb=None):
         return self.fuse_planes(_planes_of(local_embs))
 
-    def fuse_planes(self, planes, heads=1):
+    def fuse_planes(self, planes, heads=1, l2norm_planes=False):
         H = heads if any(p[1] for p in planes) else 1
         D = planes[0][0].shape[1] * (heads if planes[0][1] else 1)
-        out = ops.fuse(planes, H, D // H, None, None, None, ops.attention_flags(just_average=True))
+        out = ops.fuse(planes, H, D // H, None, None, None, ops.attention_flags(just_average=True), l2norm_planes=l2norm_planes)
         return out.view(out.shape[0], D)
 
 
@@ -61,26 +67,37 @@ class Attention_1(nn.Module):
         return (lin.weight.detach().reshape(1, -1).contiguous(), lin.bias.detach().reshape(1).contiguous(),
                 self.global_emb_weight_net.weight.detach().reshape(1).contiguous())
 
-    def fuse_planes(self, planes, heads=1):
+    def fuse_planes(self, planes, heads=1, l2norm_planes=False, record_weights=None):
+        """record_weights: also store the softmax weights (the reference's `self.weights` side output, Attention.py:90,97).  The
+        tower path leaves it off unless `self.record_weights` is set (get_attention_weight does): it is an extra N x L store per
+        launch that only that consumer reads."""
         if self.training:
             raise NotImplementedError('laff_amd implements the inference path only; call .eval()')
         w, b, gw = self._params()
         flags = ops.attention_flags(self.with_ave, self.mul)
+        if heads > 1 and any(p[1] for p in planes):
+            # a no-transform feature repeated over `heads` (model/model.py:1822-1823) in front of a single-head attention: this block
+            # sees all heads * d columns as one vector, so the tiled plane is materialised to full width first
+            planes = [(_full_width(p, heads, self.embed_dim), False, None, None) if p[1] else p for p in planes]
         packed = getattr(self, 'emit_packed', None)       # 'fp16' | 'bf16': also emit the GEMM operand (last_packed)
-        res = ops.fuse(planes, 1, self.embed_dim, w, b, gw, flags, return_weights=True, packed_precision=packed)
-        E, aw = res[0], res[1]
-        self.last_packed = res[2] if packed else None
-        aw = aw[:, 0, :]
-        if self.with_ave:   # what the reference stashes in that case (Attention.py:97)
-            aw = aw + gw / aw.shape[1]
-        self.weights = aw
+        rec = getattr(self, 'record_weights', False) if record_weights is None else record_weights
+        res = ops.fuse(planes, 1, self.embed_dim, w, b, gw, flags, return_weights=rec, packed_precision=packed,
+                       l2norm_planes=l2norm_planes)
+        res = res if isinstance(res, tuple) else (res,)
+        E = res[0]
+        self.last_packed = res[-1] if packed else None
+        if rec:
+            aw = res[1][:, 0, :]
+            if self.with_ave:   # what the reference stashes in that case (Attention.py:97)
+                aw = aw + gw / aw.shape[1]
+            self.weights = aw
         return E.view(E.shape[0], self.embed_dim)
 
     def forward(self, local_embs, raw_global_emb=None):
         if raw_global_emb is not None:
             raise NotImplementedError('raw_global_emb is never passed on the retrieval path '
                                       '(and is undefined in the reference when mul=False)')
-        return self.fuse_planes(_planes_of(local_embs))
+        return self.fuse_planes(_planes_of(local_embs), record_weights=True)
 
 
 class Multi_head_MyApply_Attention(nn.Module):
@@ -120,22 +137,27 @@ class Multi_head_MyApply_Attention(nn.Module):
             self._packed = (key, w, b, gw)
         return self._packed[1:]
 
-    def fuse_planes(self, planes, heads=None):
+    def fuse_planes(self, planes, heads=None, l2norm_planes=False, record_weights=None):
         if self.training:
             raise NotImplementedError('laff_amd implements the inference path only; call .eval()')
         w, b, gw = self._params()
         flags = ops.attention_flags(self.with_ave, self.mul, self.l2norm_each_head, self.split_head)
         packed = getattr(self, 'emit_packed', None)       # 'fp16' | 'bf16': also emit the GEMM operand (last_packed)
-        res = ops.fuse(planes, self.multi_heads, self.head_dim, w, b, gw, flags, return_weights=True, packed_precision=packed)
-        E, aw = res[0], res[1]
-        self.last_packed = res[2] if packed else None
-        for h in range(self.multi_heads):
-            a = aw[:, h, :]
-            self.attention_layer[h].weights = a + gw[h] / a.shape[1] if self.with_ave else a
+        rec = getattr(self, 'record_weights', False) if record_weights is None else record_weights
+        res = ops.fuse(planes, self.multi_heads, self.head_dim, w, b, gw, flags, return_weights=rec, packed_precision=packed,
+                       l2norm_planes=l2norm_planes)
+        res = res if isinstance(res, tuple) else (res,)
+        E = res[0]
+        self.last_packed = res[-1] if packed else None
+        if rec:
+            aw = res[1]
+            for h in range(self.multi_heads):
+                a = aw[:, h, :]
+                self.attention_layer[h].weights = a + gw[h] / a.shape[1] if self.with_ave else a
         return E
 
     def forward(self, local_embs, raw_global_emb=None, attn_mask=None):
-        return self.fuse_planes(_planes_of(local_embs))
+        return self.fuse_planes(_planes_of(local_embs), record_weights=True)
 
     def get_raw_global_emb_weight(self):
         return self.attention_layer[0].global_emb_weight_net.weight.item()

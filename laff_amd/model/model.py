@@ -218,8 +218,26 @@ def _expert_rows(embedding, n):
     return None if embedding is None else embedding.weight.detach()[:n]
 
 
-def _fuse(attention_layer, planes, heads):
+class _recording:
+    """attention layers store their softmax weights (the reference's `self.weights`) only while this is active: on the tower path
+    it is an extra store per launch that nobody but get_attention_weight() reads"""
+
+    def __init__(self, *layers):
+        self.layers = layers
+
+    def __enter__(self):
+        for l in self.layers:
+            l.record_weights = True
+
+    def __exit__(self, *a):
+        for l in self.layers:
+            l.record_weights = False
+
+
+def _fuse(attention_layer, planes, heads, l2norm_planes=False):
     if hasattr(attention_layer, 'fuse_planes'):
+        if l2norm_planes:
+            return attention_layer.fuse_planes(planes, heads, l2norm_planes=True)
         return attention_layer.fuse_planes(planes, heads)
     raise NotImplementedError('attention layer %s is outside the LAFF hot path' % type(attention_layer).__name__)
 
@@ -285,14 +303,14 @@ class VisMutiTransformNetAddAttnetion(nn.Module):
         if opt.vis_expert_embedding['expert']:
             self.expert_embedding = nn.Embedding(len(self.vis_net_space_dict), self.common_space_dim)
         if opt.vis_expert_embedding['l2norm']:
-            raise NotImplementedError('vis_expert_embedding l2norm is off in every shipped config and not provided')
+            self.expert_l2Norm = True          # l2norm(local_embs, dim=2) before the attention (model/model.py:1855-1856, 1872-1873)
 
     def prepare(self, vis_input, vis_frame_feat_dict_input=None, pending=None):
         """Queue this tower's FC projections on `pending`; returns the closure that fuses once they have run."""
         _eval_only(self)
         planes = self.VisMutiTransformNet.planes(vis_input, _expert_rows(self.expert_embedding, len(self.vis_net_space_dict)),
                                                  pending)
-        return lambda: _fuse(self.attention_layer, planes, self.opt.multi_head_attention['heads'])
+        return lambda: _fuse(self.attention_layer, planes, self.opt.multi_head_attention['heads'], self.expert_l2Norm)
 
     def forward(self, vis_input, txt_emb=None, vis_frame_feat_dict_input=None):
         pending = []
@@ -301,7 +319,8 @@ class VisMutiTransformNetAddAttnetion(nn.Module):
         return finish()
 
     def get_attention_weight(self, vis_input, txt_emb=None):
-        self.forward(vis_input, txt_emb)
+        with _recording(self.attention_layer):
+            self.forward(vis_input, txt_emb)
         return self.attention_layer.get_attention_weight()
 
 
@@ -381,8 +400,7 @@ class MultiScaleTxtEncoderAttention(nn.Module):
         self.expert_embedding = None
         if opt.txt_expert_embedding['expert']:
             self.expert_embedding = nn.Embedding(len(self.space_dict), D)
-        if opt.txt_expert_embedding['l2norm']:
-            raise NotImplementedError('txt_expert_embedding l2norm is off in every shipped config and not provided')
+        self.txt_expert_l2Norm = bool(opt.txt_expert_embedding['l2norm'])      # model/model.py:1660-1661, 1693-1694
 
     def prepare(self, caption_feat_dict, pending=None, task3=False):
         _eval_only(self)
@@ -395,8 +413,8 @@ class MultiScaleTxtEncoderAttention(nn.Module):
             planes.append(getattr(self.transform_layer, name + '_transform').plane(
                 feats, h, None if expert is None else expert[i], pending, head_dim=self.opt.txt_fc_layers[1] // heads
                 if type(self.attention_layer).__name__ == 'Multi_head_MyApply_Attention' and
-                self.attention_layer.split_head else None))
-        return lambda: _fuse(self.attention_layer, planes, heads)
+                self.attention_layer.split_head and not self.txt_expert_l2Norm else None))     # (a row norm needs the projected plane)
+        return lambda: _fuse(self.attention_layer, planes, heads, self.txt_expert_l2Norm)
 
     def forward(self, caption_feat_dict, visual_emb=None, task3=False):
         pending = []
@@ -405,7 +423,8 @@ class MultiScaleTxtEncoderAttention(nn.Module):
         return finish()
 
     def get_attention_weight(self, caption_feat_dict, visual_emb=None):
-        self.forward(caption_feat_dict, visual_emb)
+        with _recording(self.attention_layer):
+            self.forward(caption_feat_dict, visual_emb)
         return self.attention_layer.get_attention_weight()
 
 

@@ -309,11 +309,13 @@ def fc_act_bn_fused_grouped(problems):
     return outs
 
 
-def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=None):
+def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=None, l2norm_planes=False):
     """planes: list of (src[N, ld-view], tile, scale, shift[, act]) -- act ('tanh' | 'relu' | 'sigmoid' | None) is applied to src
     before the affine (a projection that left its activation + BatchNorm to this kernel).  Returns E (N, H, d) [and softmax
     weights (N, H, L)].
-    packed_precision ('fp16' | 'bf16'): also emit the similarity operand in the same launch; returned last."""
+    packed_precision ('fp16' | 'bf16'): also emit the similarity operand in the same launch; returned last.
+    l2norm_planes: every plane row is first divided by its l2 norm over all H*d columns (`l2norm(local_embs, dim=2)` of the
+    expert-embedding branch, model/model.py:1866-1873): one extra launch computes the norms (laff_plane_row_norms)."""
     L = len(planes)
     arr = (Plane * L)()
     first = planes[0]
@@ -359,6 +361,12 @@ def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=N
         if t is not None:
             _dev(t, nm)
     lib, h = _context(dev)
+    if l2norm_planes:
+        norms = torch.empty((L, max(N, 1)), device=dev, dtype=torch.float32)
+        _call('plane_row_norms', lib.laff_plane_row_norms, h, arr, L, N, H, d, flags, _ptr(norms))
+        for i in range(L):
+            arr[i].row_scale = norms[i].data_ptr()
+        keep.append(norms)
     packed = None
     if packed_precision is not None:
         prescale = default_prescale(packed_precision)

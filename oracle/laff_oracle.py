@@ -144,11 +144,17 @@ def multi_head_attention(x, w, b, gw, H, with_ave=False, mul=False, split_head=T
 # ------------------------------------------------------------------------------------------------
 # towers: a3/a4 (model/model.py:1807-1876, :1663-1705) and a7 (:2147-2190)
 # ------------------------------------------------------------------------------------------------
-def fuse_tower(feature_specs, att, H):
+def fuse_tower(feature_specs, att, H, expert=None, expert_l2norm=False):
     """feature_specs: list of dicts for transform_net (x, W, b, act, bn, tile_heads), in stack order.
-    att: dict(w, b, gw, with_ave, mul, split_head, l2norm_each_head) or {'kind': 'just_average'}."""
+    att: dict(w, b, gw, with_ave, mul, split_head, l2norm_each_head) or {'kind': 'just_average'}.
+    expert: (L, D) expert-embedding rows added to the stacked planes (:1866-1870 / :1686-1690); expert_l2norm: then
+    l2norm over D (:1872-1873 / :1693-1694)."""
     planes = [transform_net(**s) for s in feature_specs]
     local = np.stack(planes, axis=1)                        # torch.stack(dim=1) (:1862 / :1683)
+    if expert is not None:
+        local = (local + _f32(expert)[None, :local.shape[1], :]).astype(F32)
+    if expert_l2norm:
+        local = l2norm(local, axis=2)
     if att.get('kind') == 'just_average':
         return just_average(local)
     if att.get('kind') == 'attention_1':

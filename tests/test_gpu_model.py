@@ -47,6 +47,53 @@ def test_laff_towers_golden(golden):
         assert maxdiff(model.encode_video({n: t(g[k + '/vis/' + n]) for n in c['vid_dims']}), g[k + '/vis_emb']) <= 5e-6
 
 
+def test_laff_expert_embedding_golden(golden):
+    """vis/txt_expert_embedding {'expert': True, 'l2norm': False | True}: the embedding row rides in the plane's shift, the row norm
+    over all heads is one extra launch (laff_plane_row_norms) -- against the reference's towers."""
+    g = golden('laff_expert')
+    for c in g.json('cases'):
+        k = c['key']
+        cfg = make_config(c['vid_dims'], c['txt_dims'], c['D'], c['H'], 'LAFF', c['vis_no_transform'], c['txt_no_transform'],
+                          with_ave=c['with_ave'], mul=c['mul'], batch_norm=c['batch_norm'],
+                          vis_expert_embedding={'expert': True, 'l2norm': c['l2norm']},
+                          txt_expert_embedding={'expert': True, 'l2norm': c['l2norm']})
+        model = get_model('LAFF', DEV, cfg).eval()
+        res = load_sd(model, g.sub(k + '/sd/'))
+        assert not res.unexpected_keys and not res.missing_keys
+        N = g[k + '/vis_emb'].shape[0]
+        vis_in = {n: t(g[k + '/vis/' + n]) for n in c['vid_dims']}
+        cap = {'caption': ['x'] * N}
+        cap.update({TXT_KEY[n]: t(v) for n, v in g.sub(k + '/txt/').items()})
+        assert maxdiff(model.vis_net(vis_in), g[k + '/vis_emb']) <= 5e-6, c
+        assert maxdiff(model.txt_net(cap), g[k + '/txt_emb']) <= 5e-6, c
+        # the sparse bag-of-words input takes the same route (projected first when a row norm is needed)
+        sp = cap['bow_encoding'].to(DEV).float().to_sparse_csr()
+        cap_sp = dict(cap, bow_encoding=torch.sparse_csr_tensor(sp.crow_indices().to(torch.int32), sp.col_indices().to(torch.int32),
+                                                                 sp.values(), size=sp.shape))
+        assert maxdiff(model.txt_net(cap_sp), g[k + '/txt_emb']) <= 5e-6, c
+
+
+def test_attention_1_family_with_a_repeated_no_transform_feature():
+    """vis_attention of the single-vector Attention_1 family with heads > 1 and a no-transform feature: the reference repeats the
+    feature `heads` times whatever the attention type (model/model.py:1822-1823); the tiled plane is written out to full width."""
+    from laff_amd import ops
+    from laff_amd.model.Attention import Attention_1
+    g = np.random.default_rng(5)
+    N, H, d = 33, 4, 64
+    D = H * d
+    x_raw = g.normal(0, 1, (N, d)).astype(np.float32)
+    x_fc = g.normal(0, 1, (N, D)).astype(np.float32)
+    scale, shift = g.uniform(0.5, 1.5, D).astype(np.float32), g.normal(0, 0.1, D).astype(np.float32)
+    att = Attention_1(D, with_ave=False, mul=False).to(DEV).eval()
+    dv = lambda a: torch.from_numpy(a).to(DEV)
+    out = att.fuse_planes([(dv(x_raw), True, dv(scale), dv(shift)), (dv(x_fc), False, None, None)], heads=H)
+    tiled = np.tile(x_raw, (1, H)) * scale + shift
+    w = att.embedding_common[0].weight.detach().cpu().numpy().reshape(-1)
+    b = att.embedding_common[0].bias.detach().cpu().numpy().reshape(())
+    ref = O.attention_1(np.stack([tiled, x_fc], axis=1), w, b, False, False, 1.0)
+    assert maxdiff(out, ref) <= 3e-6
+
+
 def test_framelaff_golden(golden):
     g = golden('framelaff')
     for c in g.json('cases'):

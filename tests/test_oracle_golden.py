@@ -89,6 +89,21 @@ def test_laff_towers(golden):
         close(O.txt2vis_matrix_fast(te, ve), g[k + '/scores'])
 
 
+def test_laff_expert_embedding(golden):
+    """expert embeddings added to the stacked planes, with and without l2norm(dim=2) (model/model.py:1866-1873, :1686-1694)"""
+    g = golden('laff_expert')
+    for c in g.json('cases'):
+        k = c['key']
+        sd = g.sub(k + '/sd/')
+        att_v = O.attention_from_sd(sd, 'vis_net.attention_layer.', c['H'], c['with_ave'], c['mul'])
+        att_t = O.attention_from_sd(sd, 'txt_net.attention_layer.', c['H'], c['with_ave'], c['mul'])
+        ve = O.fuse_tower(_vis_specs(g, k, c, sd, 'vis_net.VisMutiTransformNet.'), att_v, c['H'],
+                          sd['vis_net.expert_embedding.weight'], c['l2norm'])
+        te = O.fuse_tower(_txt_specs(g, k, c, sd), att_t, c['H'], sd['txt_net.expert_embedding.weight'], c['l2norm'])
+        close(ve, g[k + '/vis_emb'])
+        close(te, g[k + '/txt_emb'])
+
+
 def test_framelaff(golden):
     g = golden('framelaff')
     for c in g.json('cases'):

@@ -358,6 +358,46 @@ def gen_laff_towers():
 
 
 # ----------------------------------------------------------------------------------------------
+# (4b) 'LAFF' towers with expert embeddings (model/model.py:1848-1873, :1653-1694): add, and add + l2norm(dim=2)
+# ----------------------------------------------------------------------------------------------
+def gen_laff_expert():
+    g = rng(414)
+    arrays = {}
+    cases = []
+    for idx, (l2, bn, with_ave) in enumerate([(False, False, False), (True, True, False), (True, False, True)]):
+        vid_dims = {'clip_finetune_8frame_uniform_1103': 128, 'X3D_L': 40, 'irCSN_152_ig65m_16frms': 24}
+        txt_dims = {'bow': 30, 'w2v': 20, 'CLIP': 128}
+        cfg = laff_cfg(vid_dims, txt_dims, 512, 4, with_ave, False, bn, ['clip_finetune_8frame_uniform_1103'])
+        cfg.vis_expert_embedding = {'expert': True, 'l2norm': l2}
+        cfg.txt_expert_embedding = {'expert': True, 'l2norm': l2}
+        torch.manual_seed(520 + idx)
+        model = mm.get_model('LAFF', torch.device('cpu'), cfg).eval()
+        plug_text_encoders(model)
+        randomize_model(model, g, 0.7 if with_ave else None, 0.4 if with_ave else None)
+        N = 19
+        vis = {k: f32(g.normal(0, 1, (N, d))) for k, d in vid_dims.items()}
+        txt = {'bow_feature': f32((g.uniform(0, 1, (N, 30)) < 0.1).astype(np.float32)),
+               'w2v_feature': f32(g.normal(0, 1, (N, 20))), 'CLIP_encoding': f32(g.normal(0, 1, (N, 128)))}
+        vis_emb = model.vis_net({k: torch.from_numpy(v.copy()) for k, v in vis.items()})
+        cap = {'caption': ['%d' % i for i in range(N)]}
+        cap.update({k: torch.from_numpy(v.copy()) for k, v in txt.items()})
+        txt_emb = model.txt_net(cap)
+        key = 'c%d' % idx
+        for k, v in vis.items():
+            arrays[key + '/vis/' + k] = v
+        for k, v in txt.items():
+            arrays[key + '/txt/' + k] = v
+        arrays[key + '/vis_emb'] = vis_emb.detach().numpy()
+        arrays[key + '/txt_emb'] = txt_emb.detach().numpy()
+        arrays.update(model_sd_arrays(model, key + '/sd/'))
+        cases.append({'key': key, 'vid_dims': vid_dims, 'txt_dims': txt_dims, 'D': 512, 'H': 4, 'with_ave': with_ave, 'mul': False,
+                      'batch_norm': bn, 'l2norm': l2, 'vis_no_transform': ['clip_finetune_8frame_uniform_1103'],
+                      'txt_no_transform': ['CLIP_encoder'], 'encoder_name_list': list(model.txt_net.encoder_name_list)})
+    arrays['cases'] = np.array(json.dumps(cases))
+    save('laff_expert', **arrays)
+
+
+# ----------------------------------------------------------------------------------------------
 # (5) 'FrameLAFF' tower, ragged frame counts
 # ----------------------------------------------------------------------------------------------
 def framelaff_cfg(vid_dims, frame_feats, D, H, frame_attention, addFC, batch_norm, with_video_feat=True):
@@ -818,7 +858,7 @@ GENERATORS = {
     'margin_loss': gen_margin_loss,
     'txt2vec': gen_txt2vec,
     'attention_1': gen_attention_1, 'multi_head': gen_multi_head, 'transform_net': gen_transform_net,
-    'laff_towers': gen_laff_towers, 'framelaff': gen_framelaff, 'txt2vis': gen_txt2vis,
+    'laff_towers': gen_laff_towers, 'laff_expert': gen_laff_expert, 'framelaff': gen_framelaff, 'txt2vis': gen_txt2vis,
     'predict': gen_predict, 'eval': gen_eval, 'bigfile': gen_bigfile, 'writers': gen_writers,
 }
 
