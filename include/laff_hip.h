@@ -274,7 +274,9 @@ int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const
 
 /* ---- result lists (predictor.txt2video_write_to_file, predictor.py:53-88): for every row the K best columns, score
  * descending (ties: larger column first = a stable ascending argsort read backwards), instead of a full-matrix argsort.
- * idx_out [Nt,K] int32, val_out [Nt,K] fp32.  1 <= K <= min(Nv, 2048); (Nv + K') * 8 bytes of LDS must fit 160 KiB. */
+ * idx_out [Nt,K] int32, val_out [Nt,K] fp32.  1 <= K <= min(Nv, 8192); the row (4 Nv bytes) + 8 K' bytes (K' = K rounded up to
+ * 64 / 512 / 2048 / 4096 / 8192) must fit 160 KiB of LDS: wider collections are split by columns and the per-block lists merged with a
+ * second call (laff_amd.ops.topk_rows does; LAFF_E_UNSUPPORTED says how many columns fit). */
 int laff_topk_rows(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, int K, int* idx_out, float* val_out);
 
 /* ---- a13: evaluation.eval (evaluation.py:92-109) for single-GT rows ---------------------------------------

@@ -639,8 +639,13 @@ int laff_topk_rows(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, int K
     CHECK_CTX(ctx);
     if (Nt == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (!S || !idx_out || !val_out) return fail(LAFF_E_ARG, "laff_topk_rows: null argument");
-    if (Nt < 0 || Nv < 1 || lds < Nv || K < 1 || K > Nv || K > 2048) return fail(LAFF_E_SHAPE, "laff_topk_rows: need 1 <= K <= min(Nv, 2048) (Nt=%d Nv=%d K=%d)", Nt, Nv, K);
-    if ((size_t)Nv * 4 + 2048 * 8 + 2048 > 160 * 1024) return fail(LAFF_E_UNSUPPORTED, "laff_topk_rows: Nv=%d does not fit the LDS-resident row (max ~36k columns per shard)", Nv);
+    if (Nt < 0 || Nv < 1 || lds < Nv || K < 1 || K > Nv || K > 8192) return fail(LAFF_E_SHAPE, "laff_topk_rows: need 1 <= K <= min(Nv, 8192) (Nt=%d Nv=%d K=%d)", Nt, Nv, K);
+    {
+        const size_t kp = K <= 64 ? 64 : (K <= 512 ? 512 : (K <= 2048 ? 2048 : (K <= 4096 ? 4096 : 8192)));
+        if ((size_t)((Nv + 3) & ~3) * 4 + kp * 8 + 256 * 4 + 16 > 160 * 1024)
+            return fail(LAFF_E_UNSUPPORTED, "laff_topk_rows: Nv=%d with K=%d does not fit the LDS-resident row (%zu columns at most: split the "
+                        "columns and merge the per-block lists, as laff_amd.ops.topk_rows does)", Nv, K, (160 * 1024 - kp * 8 - 1040) / 4);
+    }
     if (Nt == 0) return LAFF_OK;
     DeviceGuard g(ctx->device);
     HIP_TRY(laff::launch_topk_rows(S, Nt, Nv, lds, K, idx_out, val_out, ctx->stream));

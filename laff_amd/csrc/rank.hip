@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 }
 
 hipError_t launch_topk_rows(const float* S, int Nt, int Nv, int lds, int K, int* idx_out, float* val_out, hipStream_t st) {
-    if (K > 2048) return hipErrorInvalidValue;
+    if (K > 8192) return hipErrorInvalidValue;
 #define LAFF_TOPK(P)                                                                                                     \
     do {                                                                                                                 \
         const size_t smem = (size_t)((Nv + 3) & ~3) * 4 + (size_t)(P) * 8 + 256 * 4 + 16;                                  \
@@ -672,7 +672,9 @@ hipError_t launch_topk_rows(const float* S, int Nt, int Nv, int lds, int K, int*
     } while (0)
     if (K <= 64) LAFF_TOPK(64);
     else if (K <= 512) LAFF_TOPK(512);
-    else LAFF_TOPK(2048);
+    else if (K <= 2048) LAFF_TOPK(2048);
+    else if (K <= 4096) LAFF_TOPK(4096);
+    else LAFF_TOPK(8192);
 #undef LAFF_TOPK
     return hipGetLastError();
 }

@@ -38,20 +38,53 @@ GATHER_IN_FUSE = os.environ.get('LAFF_GATHER_IN_FUSE', '1') != '0'
 FUSED_SPLIT = os.environ.get('LAFF_FUSED_SPLIT', '1') != '0'
 
 
+def _row_chunks(pending, limit_bytes=1 << 31):
+    """The split-product GEMMs address an operand with 32-bit byte offsets (the C ABI refuses a packed operand of 4 GiB or more:
+    300k x 4096 fp32 rows already exceed it).  Row blocks are independent, so an oversized problem is cut into row chunks that share
+    its weights and write into views of its output -- same results, a few more tiles in the grouped launch."""
+    out = []
+    for q in pending:
+        x = q['x']
+        if not torch.is_tensor(x) or x.layout != torch.strided or x.dim() != 2:
+            out.append(q)
+            continue
+        n, k = x.shape
+        row_bytes = 4 * max(x.stride(0) if n > 1 else k, (k + 63) // 64 * 64)
+        if n * row_bytes < limit_bytes:
+            out.append(q)
+            continue
+        if q.get('out') is None:
+            q['out'] = torch.empty((n, q['weight'].shape[0]), device=x.device, dtype=torch.float32)
+        step = max(256, (limit_bytes // row_bytes) // 256 * 256)
+        for a in range(0, n, step):
+            out.append(dict(q, x=x[a:a + step], out=q['out'][a:a + step]))
+    return out
+
+
 def run_fc(pending):
     """Launch every queued FC projection as one grouped GEMM."""
     if FC_PRECISION == 'fp16x3':
-        # big launches with a narrow output take the fused split (inputs stay fp32 in HBM, split inside the GEMM: every column
-        # tile of a row block repeats the conversion, 2x at D = 512 but 16x at D = 4096, where materialising the planes once is
-        # cheaper: C5 33.2 ms fused vs 32.9 ms); small launches take the materialised split, whose 128x128 tiles fill the chip
-        tiles = sum(((q['x'].shape[0] + 255) // 256) * ((q['weight_split'].N + 255) // 256) for q in pending)
-        if (FUSED_SPLIT and tiles >= 512 and all(q['weight_split'].N <= 1024 for q in pending) and
-                all(ops.fused_split_eligible(q['x'], q['weight_split']) for q in pending)):
-            return ops.fc_act_bn_fused_grouped(pending)
-        return ops.fc_act_bn_split_grouped(pending)
+        whole = pending
+        pending = _row_chunks(pending)
+        if len(pending) != len(whole):          # chunked: launch the pieces, hand back one output per original problem
+            outs = _run_fc_x3(pending)
+            by_id = {id(q): o for q, o in zip(pending, outs)}
+            return [q['out'] if q.get('out') is not None else by_id[id(q)] for q in whole]
+        return _run_fc_x3(pending)
     if FC_PRECISION != 'fp32':
         raise ValueError("FC_PRECISION must be 'fp32' or 'fp16x3'")
     return ops.fc_act_bn_grouped(pending)
+
+
+def _run_fc_x3(pending):
+    # big launches with a narrow output take the fused split (inputs stay fp32 in HBM, split inside the GEMM: every column
+    # tile of a row block repeats the conversion, 2x at D = 512 but 16x at D = 4096, where materialising the planes once is
+    # cheaper: C5 33.2 ms fused vs 32.9 ms); small launches take the materialised split, whose 128x128 tiles fill the chip
+    tiles = sum(((q['x'].shape[0] + 255) // 256) * ((q['weight_split'].N + 255) // 256) for q in pending)
+    if (FUSED_SPLIT and tiles >= 512 and all(q['weight_split'].N <= 1024 for q in pending) and
+            all(ops.fused_split_eligible(q['x'], q['weight_split']) for q in pending)):
+        return ops.fc_act_bn_fused_grouped(pending)
+    return ops.fc_act_bn_split_grouped(pending)
 
 
 #: tower path: leave activation + BatchNorm of the FC projections to the fuse launch (see TransformNet.plane).  Off by default:

@@ -616,8 +616,16 @@ def rank_count(S, gt_col, s_gt, col0=0, count=None):
     return count
 
 
-def topk_rows(S, K):
-    """Per row: indices (int32) and scores (fp32) of the K best columns, score descending, ties by larger index first."""
+def _topk_kp(K):
+    return 64 if K <= 64 else (512 if K <= 512 else (2048 if K <= 2048 else (4096 if K <= 4096 else 8192)))
+
+
+def topk_max_columns(K):
+    """columns of one laff_topk_rows call: the row lives in LDS next to the K' selected (key, index) pairs"""
+    return (160 * 1024 - _topk_kp(K) * 8 - 1040) // 4
+
+
+def _topk_call(S, K):
     S, lds = _rows(S, 'S')
     Nt, Nv = S.shape
     idx = torch.empty((Nt, K), device=S.device, dtype=torch.int32)
@@ -625,6 +633,42 @@ def topk_rows(S, K):
     lib, h = _context(S.device)
     _call('topk_rows', lib.laff_topk_rows, h, _ptr(S), Nt, Nv, lds, int(K), _ptr(idx), _ptr(val))
     return idx, val
+
+
+def topk_rows(S, K):
+    """Per row: indices (int32) and scores (fp32) of the K best columns, score descending, ties by larger index first (what the
+    reference's `np.argsort(...)[::-1][:K]` yields with a stable sort, predictor.py:53-65).  Any number of columns: a collection that
+    does not fit the kernel's LDS-resident row (~36k columns at K <= 2048) is split into column blocks, each block's K best are
+    taken, and the lists are merged by the same kernel -- block lists are laid out in ascending (score, index) order and blocks in
+    column order, so that position order equals index order among equal scores and the tie rule carries over.  K <= 8192."""
+    S, lds = _rows(S, 'S')
+    Nt, Nv = S.shape
+    K = int(K)
+    if K < 1 or K > Nv or K > 8192:
+        raise ValueError('topk_rows: need 1 <= K <= min(Nv, 8192), got K=%d for %d columns' % (K, Nv))
+    cap = topk_max_columns(K)
+    if Nv <= cap:
+        return _topk_call(S, K)
+    vals, idxs = [], []
+    for c0 in range(0, Nv, cap):
+        blk = S[:, c0:min(Nv, c0 + cap)]
+        k = min(K, blk.shape[1])
+        i, v = _topk_call(blk, k)
+        vals.append(v.flip(1))
+        idxs.append((i + c0).flip(1))
+    cand_v, cand_i = torch.cat(vals, dim=1).contiguous(), torch.cat(idxs, dim=1).contiguous()
+    while cand_v.shape[1] > cap:             # very wide collections: merge groups of block lists first
+        group = max(2, cap // K) * K
+        nv, ni = [], []
+        for c0 in range(0, cand_v.shape[1], group):
+            pv, pi = cand_v[:, c0:c0 + group], cand_i[:, c0:c0 + group]
+            k = min(K, pv.shape[1])
+            p, v = _topk_call(pv, k)
+            nv.append(v.flip(1))
+            ni.append(torch.gather(pi, 1, p.long()).flip(1))
+        cand_v, cand_i = torch.cat(nv, dim=1).contiguous(), torch.cat(ni, dim=1).contiguous()
+    pos, val = _topk_call(cand_v, K)
+    return torch.gather(cand_i, 1, pos.long()).contiguous(), val
 
 
 def v2t_count(S, grp_off, grp_idx, max_group):

@@ -373,13 +373,16 @@ def test_fuse_emits_the_packed_operand():
         assert maxdiff(S1, S2) <= (1e-4 if prec == 'fp16' else 2e-3)
 
 
-@pytest.mark.parametrize('Nt,Nv,K', [(7, 30, 10), (50, 10000, 500), (9, 3000, 2000), (5, 33, 32), (3, 5, 1)])
+@pytest.mark.parametrize('Nt,Nv,K', [(7, 30, 10), (50, 10000, 500), (9, 3000, 2000), (5, 33, 32), (3, 5, 1),
+                                     (6, 80000, 500), (4, 50000, 3000), (3, 300000, 2000), (2, 20000, 8192)])   # wider than one LDS row: split + merge
 def test_topk_rows_vs_argsort(Nt, Nv, K):
     from laff_amd import ops
     g = rnd(Nt + Nv + K)
     S = g.normal(0, 0.2, (Nt, Nv)).astype(np.float32)
     S[0, :min(5, Nv)] = S[0, min(7, Nv - 1)]     # ties, some of them across the K boundary for small K
     S[1 % Nt, -1] = np.float32(-0.0)
+    if Nv > 40000:                               # ties between column blocks, at the top of the list
+        S[Nt - 1, [11, 36000, Nv - 5]] = 9.0
     idx, val = ops.topk_rows(dev(S), K)
     ref = np.argsort(S, axis=1, kind='stable')[:, ::-1][:, :K]
     assert np.array_equal(idx.cpu().numpy(), ref)

@@ -298,3 +298,45 @@ def test_bench_line_contract():
     assert line['sustained']['seconds'] >= 1.9
     assert {v['kind'] for v in line['cpu_baseline']['variants']} == {'port-blockloop-argsort', 'port-vectorised'}
     assert abs(line['cpu_baseline']['r1'] - line['quality']['R@1']) < 1e-9
+
+
+def test_evaluation_cosine_sim_golden(golden):
+    """laff_amd.evaluation.cosine_sim (GPU-backed, numpy in / numpy out) against the reference's evaluation.cosine_sim
+    (evaluation.py:44-49), every operand precision; a zero query row and one whose norm is comparable to the 1e-10 epsilon."""
+    from laff_amd import evaluation
+    g = golden('eval_cosine')
+    for prec, tol in (('fp16x3', 2e-6), ('fp32', 2e-6), ('bf16x3', 5e-6), ('fp16', 4e-4)):     # d = 96: 16-bit rounding ~ 1/sqrt(d)
+        got = evaluation.cosine_sim(g['q'], g['r'], precision=prec)
+        assert isinstance(got, np.ndarray) and got.dtype == np.float32
+        assert np.abs(got - g['sim']).max() <= tol, prec
+        assert np.all(got[3] == 0.0)
+    assert np.abs(evaluation.compute_sim(g['q'], g['r']) - g['sim']).max() <= 2e-6
+    with pytest.raises(NotImplementedError):
+        evaluation.compute_sim(g['q'], g['r'], measure='hist')
+
+
+def test_oversized_fc_problem_is_cut_into_row_chunks():
+    """FC_PRECISION 'fp16x3' on a feature matrix whose packed operand would pass the C ABI's 4 GiB limit: run_fc cuts it into row
+    chunks (here the limit is lowered instead of allocating 4 GiB) -- same output as the uncut launch, preallocated `out` honoured."""
+    import laff_amd.model.model as M
+    from laff_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(5000, 256, device=DEV)
+    W = torch.randn(192, 256, device=DEV) / 16
+    b = torch.randn(192, device=DEV) * 0.1
+    ws = ops.split_rows(W)
+    ref = ops.fc_act_bn_split_grouped([dict(x=x, weight=W, weight_split=ws, bias=b, activation='tanh')])[0]
+    out = torch.empty_like(ref)
+    probs = [dict(x=x, weight=W, weight_split=ws, bias=b, activation='tanh', out=out),
+             dict(x=x[:100], weight=W, weight_split=ws, bias=b, activation='tanh')]
+    chunks = M._row_chunks(probs, limit_bytes=1 << 20)
+    assert len(chunks) > 3 and sum(c['x'].shape[0] for c in chunks) == 5100
+    M.FC_PRECISION = 'fp16x3'
+    try:
+        old = M._row_chunks
+        M._row_chunks = lambda p: old(p, limit_bytes=1 << 20)
+        got = M.run_fc(probs)
+    finally:
+        M.FC_PRECISION = 'fp32'
+        M._row_chunks = old
+    assert got[0] is out and torch.equal(out, ref) and torch.equal(got[1], ref[:100])

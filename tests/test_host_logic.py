@@ -203,3 +203,8 @@ def test_gw_linear_decay_per_epoch():
         sd = layer.state_dict()
         vals = [float(x) for k, x in sd.items() if k.endswith('global_emb_weight_net.weight')]
         assert len(vals) == 2 and len(set(vals)) == 1
+
+
+def test_evaluation_l2norm_golden(golden):
+    g = golden('eval_cosine')
+    np.testing.assert_allclose(evaluation.l2norm(g['q']), g['l2q'], rtol=0, atol=1e-6)

@@ -234,3 +234,10 @@ def test_margin_ranking_loss_oracle_matches_reference_autograd(golden):
         assert np.abs(d_s - g[k + '/d_s']).max() <= 2e-6, c
         assert np.abs(d_im - g[k + '/d_im']).max() <= 2e-6, c
         assert float(g[k + '/loss']) > 0 and np.abs(g[k + '/d_s']).max() > 0      # the fixture exercises violations
+
+
+def test_eval_cosine_numpy_api(golden):
+    """evaluation.l2norm / evaluation.cosine_sim (evaluation.py:11-16, 44-49), incl. a zero and a near-epsilon query row"""
+    g = golden('eval_cosine')
+    close(O.np_l2norm(g['q']), g['l2q'], 1e-6)
+    close(O.np_cosine_sim(g['q'], g['r']), g['sim'], 1e-6)

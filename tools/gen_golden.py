@@ -693,6 +693,17 @@ def gen_eval():
     save('eval', **arrays)
 
 
+# (9b) evaluation.cosine_sim / evaluation.l2norm (numpy API, evaluation.py:11-16, 44-49)
+def gen_eval_cosine():
+    g = rng(818)
+    q = f32(g.normal(0, 1, (37, 96)))
+    r = f32(g.normal(0, 1, (53, 96)))
+    q[3] = 0.0                      # a zero query: the 1e-10 in the denominator decides what comes out
+    q[5] *= 1e-9                    # a tiny one: |x| comparable to the epsilon
+    r[7] *= 3e4
+    save('eval_cosine', q=q, r=r, sim=np.asarray(ref_eval.cosine_sim(q, r)), l2q=np.asarray(ref_eval.l2norm(q)))
+
+
 # ----------------------------------------------------------------------------------------------
 # (10) BigFile
 # ----------------------------------------------------------------------------------------------
@@ -858,7 +869,7 @@ GENERATORS = {
     'margin_loss': gen_margin_loss,
     'txt2vec': gen_txt2vec,
     'attention_1': gen_attention_1, 'multi_head': gen_multi_head, 'transform_net': gen_transform_net,
-    'laff_towers': gen_laff_towers, 'laff_expert': gen_laff_expert, 'framelaff': gen_framelaff, 'txt2vis': gen_txt2vis,
+    'laff_towers': gen_laff_towers, 'laff_expert': gen_laff_expert, 'eval_cosine': gen_eval_cosine, 'framelaff': gen_framelaff, 'txt2vis': gen_txt2vis,
     'predict': gen_predict, 'eval': gen_eval, 'bigfile': gen_bigfile, 'writers': gen_writers,
 }
 
