@@ -114,10 +114,18 @@ class BulkVisLoader:
     def __len__(self):
         return (len(self.vis_ids) + self.batch_size - 1) // self.batch_size
 
+    def whole(self):
+        """The whole collection as ONE batch dict: model.retrieve() / predict() then run each tower once over the full matrices (one
+        grouped FC launch, one fuse launch per side) instead of once per batch."""
+        return next(self._batches(max(1, len(self.vis_ids))), None)
+
     def __iter__(self):
+        return self._batches(self.batch_size)
+
+    def _batches(self, batch_size):
         n = len(self.vis_ids)
-        for s in range(0, n, self.batch_size):
-            ids = self.vis_ids[s:s + self.batch_size]
+        for s in range(0, n, batch_size):
+            ids = self.vis_ids[s:s + batch_size]
             feats = {name: _to_device(bf.read_matrix(ids), self.device, self.pin) for name, bf in self.files.items()}
             frame_dict = {}
             if self.frame_files:
@@ -164,10 +172,17 @@ class BulkTxtLoader:
     def __len__(self):
         return (len(self.cap_ids) + self.batch_size - 1) // self.batch_size
 
+    def whole(self):
+        """All captions as ONE (caption_feat_dict, idxs, cap_ids) batch (see BulkVisLoader.whole)."""
+        return next(self._batches(max(1, len(self.cap_ids))), None)
+
     def __iter__(self):
+        return self._batches(self.batch_size)
+
+    def _batches(self, batch_size):
         n = len(self.cap_ids)
-        for s in range(0, n, self.batch_size):
-            ids = self.cap_ids[s:s + self.batch_size]
+        for s in range(0, n, batch_size):
+            ids = self.cap_ids[s:s + batch_size]
             cap = {'caption': [self.dataset.captions[i] for i in ids]}
             for key, bf in self.files.items():
                 cap[key] = _to_device(bf.read_matrix(ids), self.device, self.pin)

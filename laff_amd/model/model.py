@@ -625,28 +625,71 @@ class W2VVPP(nn.Module):
             vis_ids.extend(batch_vis_ids)
         return torch.cat(embs, dim=0), idxs_list, vis_ids
 
+    #: operand precision of retrieve() / predict() when none is given: the score matrix of the drop-in path goes to the host anyway
+    #: (1.6 GB over PCIe at C4 is 40x the GEMM), so it takes the split-product GEMM whose scores are fp32-class (~2e-7) like the
+    #: reference's own; bench.py / retrieval.evaluate choose their precision themselves
+    predict_precision = 'fp16x3'
+
+    def _embed_whole(self, vis_loader, txt_loader):
+        """Both towers once over the whole matrices of loaders that can hand them over (`whole()`: laff_amd.data.Bulk*Loader):
+        every FC projection of both towers in ONE grouped launch, one fuse launch per side -- instead of one launch set per
+        loader batch (780 of them at C4 with the shipped batch size of 64, shell/retrieval_task.sh:161).  Row-wise arithmetic, so the
+        embeddings are bit-identical to the per-batch route on tiles of the same kind."""
+        out, (cap, _, txt_ids) = vis_loader.whole(), txt_loader.whole()
+        pending = []
+        fin_v = self.vis_net.prepare(out['vis_feat_dict'], out.get('vis_frame_feat_dict', {}), pending)
+        fin_t = self.txt_net.prepare(cap, pending)
+        run_fc(pending)
+        return fin_v(), [list(out['idxs'])], list(out['vis_ids']), fin_t(), list(txt_ids)
+
     def retrieve(self, txt_loader, vis_loader, measure='cosine', record_emb=False, precision=None):
-        """Device-resident version of predict(): returns (S_device (Nt,Nv) fp32, txt_ids, vis_ids)."""
+        """Device-resident version of predict(): returns (S_device (Nt,Nv) fp32, txt_ids, vis_ids).
+
+        When every caption id names its video the reference's way (`txt_id.split('#')[0]` in vis_ids, predictor.py:241), S is
+        produced by the exact-rank pipeline: the text->video ranks counted from it (predictor.t2v_ranks, or an argsort on the host
+        as the reference does) are the ranks of the exact cosine scores whatever the operand precision; they are also kept in
+        `self.last_t2v_ranks`."""
         if measure != 'cosine':
             raise NotImplementedError("measure '%s'" % measure)
         self.eval()
         if not hasattr(self, 'video_all_embs'):
             self.video_all_embs = None
             self.video_idxs_list = []
+        precision = precision or self.sim_precision or self.predict_precision
         with torch.no_grad():
-            if not record_emb or self.video_all_embs is None:
-                self.video_all_embs, self.video_idxs_list, self.vis_ids = self._embed_videos(vis_loader)
-            txt_ids, txt_embs = [], []
-            for caption_feat_dict, txt_idxs, batch_txt_ids in txt_loader:
-                txt_embs.append(self.txt_net(caption_feat_dict))
-                txt_ids.extend(batch_txt_ids)
-            txt_all = torch.cat(txt_embs, dim=0)
+            whole = (hasattr(vis_loader, 'whole') and hasattr(txt_loader, 'whole') and len(vis_loader.dataset) > 0 and
+                     len(txt_loader.dataset) > 0 and (not record_emb or self.video_all_embs is None))
+            if whole:
+                self.video_all_embs, self.video_idxs_list, self.vis_ids, txt_all, txt_ids = self._embed_whole(vis_loader, txt_loader)
+            else:
+                if not record_emb or self.video_all_embs is None:
+                    self.video_all_embs, self.video_idxs_list, self.vis_ids = self._embed_videos(vis_loader)
+                txt_ids, txt_embs = [], []
+                for caption_feat_dict, txt_idxs, batch_txt_ids in txt_loader:
+                    txt_embs.append(self.txt_net(caption_feat_dict))
+                    txt_ids.extend(batch_txt_ids)
+                txt_all = torch.cat(txt_embs, dim=0)
             cols = np.concatenate([np.asarray(i, dtype=np.int64) for i in self.video_idxs_list])
             vis_used = self.video_all_embs
             identity = np.array_equal(cols, np.arange(len(cols)))
             if not identity:   # the reference indexes the cached embeddings BY dataset index (:1066)
                 vis_used = self.video_all_embs[torch.as_tensor(cols, device=self.video_all_embs.device)]
-            S = self.get_txt2vis_matrix(txt_all, vis_used, measure, precision)
+            self.last_t2v_ranks = None
+            owner = None
+            if identity and len(txt_ids) and len(self.vis_ids) == vis_used.shape[0]:
+                from ..predictor import gt_columns
+                try:
+                    owner = gt_columns(txt_ids, self.vis_ids)
+                except (IndexError, ValueError, AttributeError):
+                    owner = None                 # ids do not follow the protocol: plain scores
+            if owner is not None:
+                T = ops.pack_rows(to_device_and_float16(txt_all).contiguous(), True, 1e-13, precision)
+                V = ops.pack_rows(to_device_and_float16(vis_used).contiguous(), True, 1e-13, precision)
+                gt = torch.as_tensor(owner, dtype=torch.int32, device=T.buf.device)
+                S, count, _ = ops.exact_ranks(txt_all.contiguous(), vis_used.contiguous(), T, V, gt)
+                self.last_t2v_ranks = count + 1
+            else:
+                S = self.get_txt2vis_matrix(txt_all, vis_used, measure, precision)
             if not identity:
                 full = torch.zeros((S.shape[0], len(vis_loader.dataset)), device=S.device, dtype=S.dtype)
                 full[:, torch.as_tensor(cols, device=S.device)] = S

@@ -96,6 +96,40 @@ def test_predict_from_disk_equals_device_pipeline(tmp_path):
     assert abs(t2v[0] - res.metrics[0]) <= 0.5 and t2v[3] == res.metrics[3]
 
 
+class _NoWhole:
+    """a loader without the whole() shortcut: retrieve() falls back to one tower pass per batch, like the reference"""
+
+    def __init__(self, inner):
+        self.inner, self.dataset, self.batch_size = inner, inner.dataset, inner.batch_size
+
+    def __len__(self):
+        return len(self.inner)
+
+    def __iter__(self):
+        return iter(self.inner)
+
+
+@pytest.mark.gpu
+def test_whole_matrix_route_equals_per_batch_route(tmp_path):
+    """Bulk loaders hand retrieve() the whole matrices (one grouped FC launch, one fuse per side); the embeddings are bit-for-bit
+    those of the per-batch route, the scores and the exact ranks are therefore identical too."""
+    from laff_amd import predictor, synth
+    vis_ids, feats, cap_ids, tfe, capfile = _dataset(tmp_path, Nv=300, per=4)
+    dev = torch.device('cuda')
+    model = synth.build_model(1, 512, dev)
+    vl = BulkVisLoader({n: BigFile(str(tmp_path / 'vis' / n)) for n in synth.VID_FEATS}, vis_ids, batch_size=64)
+    tl = BulkTxtLoader(capfile, {k: BigFile(str(tmp_path / 'txt' / k)) for k in tfe}, batch_size=64)
+    whole = vl.whole()
+    assert len(whole['vis_ids']) == 300 and whole['idxs'] == list(range(300))
+    S_w, txt_w, vis_w = model.retrieve(tl, vl)
+    emb_w, ranks_w = model.video_all_embs.clone(), model.last_t2v_ranks.clone()
+    S_b, txt_b, vis_b = model.retrieve(_NoWhole(tl), _NoWhole(vl))
+    assert list(txt_w) == list(txt_b) == cap_ids and list(vis_w) == list(vis_b) == vis_ids
+    assert torch.equal(model.video_all_embs, emb_w)
+    assert torch.equal(S_w, S_b) and torch.equal(model.last_t2v_ranks, ranks_w)
+    assert torch.equal(predictor.t2v_ranks(S_w, predictor.gt_columns(txt_w, vis_w)), ranks_w)
+
+
 def test_npy_features_stand_in_for_a_bigfile(tmp_path):
     """The numpy forms the reference reads (pickled {id: vector} dict, trainer.py:144-148; plain array + ids) behind the BigFile
     surface of the bulk loaders."""

@@ -171,17 +171,22 @@ def test_predict_golden(golden):
     assert maxdiff(model.video_all_embs, g['video_all_embs']) <= 5e-6
     # cached video embeddings are reused for the next query set (record_emb, model/model.py:1026-1034)
     before = model.video_all_embs.data_ptr()
-    model.sim_precision = None     # default fp16 operands: inside the 1e-4 contract
+    model.sim_precision = 'fp16'   # single-pass fp16 operands: scores inside the 1e-4 contract, text->video ranks still exact
     scores16, _, _ = model.predict(tl, vl, 'cosine', record_emb=True)
     assert model.video_all_embs.data_ptr() == before
     assert maxdiff(scores16, g['scores']) <= 1e-4
-    S, _, _ = model.retrieve(tl, vl, record_emb=True, precision='fp16x3')
+    model.sim_precision = None     # predict()'s own default: the split-product GEMM
+    S, _, _ = model.retrieve(tl, vl, record_emb=True)
+    assert maxdiff(S, g['scores']) <= 5e-6
     t2v, v2t = predictor.retrieval_metrics(S, out_txt, out_vis)
     np.testing.assert_allclose(t2v, g['t2v_metrics'], rtol=0, atol=1e-9)
     np.testing.assert_allclose(v2t, g['v2t_metrics'], rtol=0, atol=1e-9)
-    S16, _, _ = model.retrieve(tl, vl, record_emb=True)
+    ranks_x3 = model.last_t2v_ranks.clone()
+    assert torch.equal(predictor.t2v_ranks(S, predictor.gt_columns(out_txt, out_vis)), ranks_x3)    # S recounts to the exact ranks
+    S16, _, _ = model.retrieve(tl, vl, record_emb=True, precision='fp16')
     t2v16, v2t16 = predictor.retrieval_metrics(S16, out_txt, out_vis)
-    np.testing.assert_allclose(t2v16[:4], g['t2v_metrics'][:4], rtol=0, atol=1e-12)   # R@1/5/10/MedR identical with fp16 operands
+    np.testing.assert_allclose(t2v16, g['t2v_metrics'], rtol=0, atol=1e-9)     # all seven: the ranks are exact whatever the operands
+    assert torch.equal(model.last_t2v_ranks, ranks_x3)
     heads, _, _ = model.predict_each_head(tl, vl, 'cosine')
     assert maxdiff(heads.mean(axis=0), g['scores']) <= 1e-4
 
