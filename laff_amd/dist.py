@@ -342,7 +342,11 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
             gathered = state['gathered_v']
             dist.all_gather_into_tensor(gathered, send, group=group)
         mark('all_gather_wait')
-        gt_local = gt[t0:t1].contiguous()
+        # this rank's slice of the ground-truth columns lives in `state`: a captured phase reads it at a fixed address on every replay
+        key = (gt.data_ptr(), t0, t1)
+        if state.get('gt_local_key') != key:
+            state['gt_local_key'], state['gt_local'] = key, gt[t0:t1].contiguous()
+        gt_local = state['gt_local']
 
         def rank_phase():
             if comm:
