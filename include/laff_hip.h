@@ -240,12 +240,16 @@ int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv,
  *   laff_rank_prepare      Et [Nt, H, d], Ev [Nv, H, d]: the fp32 embeddings (rows 16-byte aligned, d % 4 == 0); T, V: the GEMM
  *                          operands made from them (laff_pack_rows / laff_fuse_packed; `precision`, `prescale` as given there).
  *                          Writes s_gt64[t] = exact(t, gt_col[t] - col0) (-inf when that column is outside [0, Nv): another
- *                          shard owns it -- all-reduce MAX the doubles), band_t [Nt] and band_v [Nv] with
+ *                          shard owns it -- all-reduce MAX the doubles), band_t [Nt] and band_v [Nv + ceil(Nv / 64)] with
  *                          |S_gemm(t, v) - exact(t, v)| <= band_t[t] + band_v[v]  (measured operand rounding error of both rows by
- *                          Cauchy-Schwarz + the fp32 accumulation bound), clears zero_count [Nt] (nullable) and the pair-list header.
+ *                          Cauchy-Schwarz + the fp32 accumulation bound; behind the Nv per-column values: the maximum of every
+ *                          aligned block of 64 columns, which is what the GEMM epilogue uses), clears zero_count [Nt] (nullable)
+ *                          and the pair-list header.
  *   laff_sim_gemm_banded   laff_sim_gemm whose fused count is exact-decidable: count[t] += #{v != gt : S > s_gt + band}, pairs with
- *                          |S - s_gt| <= band are appended to `pairs` (uint32: header {n, overflow, 0, 0} then {row, col} x pair_cap;
- *                          col is shard-local); S (nullable) receives (float)s_gt64 at the ground-truth entry.
+ *                          |S - s_gt| <= band are listed in `pairs` (uint32: header {n_extra, overflow, A, w} then pair_cap x
+ *                          {row, col}, col shard-local: A slots in per-wavefront segments of w slots -- valid pairs first, unused
+ *                          slots have row 0xffffffff -- then n_extra pairs appended by wavefronts whose segment was too small);
+ *                          S (nullable) receives (float)s_gt64 at the ground-truth entry.
  *   laff_rank_resolve      re-scores the listed pairs: count[row] += exact > s_gt64[row]; S (nullable) takes the fp32 value of the
  *                          exact score (one ulp above (float)s_gt64 where rounding would hide a strict inequality) so that ranks
  *                          recounted from S equal count + 1.  More than pair_cap pairs: pairs[1] = 1 and count[0] is poisoned

@@ -43,10 +43,10 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0, 0, 0, 0};
 
 constexpr int ROWB = 128;   // bytes of K per row per K-step
 
-// Similarity kernels only: a staging list for the pairs inside the error band, placed BEYOND the operand ring (the ring is still
-// being read when the first waves reach the epilogue).  Layout: {count, global base, -, -} then PAIR_LCAP x {row, col}.  One global
-// atomicAdd per TILE publishes the list: appending every pair with its own atomic on the one global counter serialised the whole
-// launch (92k pairs at C4 x ~12 ns = 1.1 ms for a 0.6 ms kernel).
+// Similarity kernels only: staging lists for the pairs inside the error band, placed BEYOND the operand ring (the ring is still
+// being read when the first waves reach the epilogue): one list of PAIR_LCAP / waves {row, col} pairs per wave.  (Appending every
+// pair with its own atomic on the one global counter serialised the whole launch: 92k pairs at C4 x ~12 ns = 1.1 ms for a 0.6 ms
+// kernel; a returning atomic per tile still cost its round trip at the very end of every tile.)
 constexpr int PAIR_LCAP = 1024;
 constexpr int PAIR_LDS = 16 + PAIR_LCAP * 8;
 // slots per tile segment: half of the list is split evenly between the tiles, the other half takes the overflow
@@ -176,126 +176,28 @@ enum { EPI_SIM = 0, EPI_FC = 1 };
 
 template <int EPI, bool FULL, typename CF>
 __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM][CF::WN], int r0, int c0, int wr, int wc,
-                                         int wave, int lane, char* smem, const float (&bc_pre)[CF::WN / 2]) {
+                                         int wave, int lane, char* smem) {
     constexpr int WM = CF::WM, WN = CF::WN, PITCH = CF::PITCH;
     const int l31 = lane & 31, hh = lane >> 5;
     float* slab = (float*)smem + wave * (32 * PITCH);
     const int cw0 = c0 + wc * (WN * 32);               // first output column of this wave
-    const bool banded = EPI == EPI_SIM && a.count != nullptr && a.s_gt64 != nullptr;
-    const bool counting = EPI == EPI_SIM && a.count != nullptr && !banded;
-    // banded count: the column part of the band as ONE value per wave (max over the wave's WN*32 columns): the per-element test is
-    // then a compare against a per-row constant, as cheap as the plain count
-    // (the band_c values were fetched before the K loop: a global load here would sit on the tile's critical path)
-    float bcmax = 0.0f;
-    unsigned* plist = (unsigned*)(smem + CF::SMEM);
-    const unsigned chunk = banded ? pair_chunk(a.pair_cap, gridDim.x) : 0u;
-    const size_t ovf_base = (size_t)gridDim.x * chunk;                      // the overflow region starts behind the tile segments
-    if (banded) {
-#pragma unroll
-        for (int i = 0; i < WN / 2; ++i) bcmax = fmaxf(bcmax, bc_pre[i]);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) bcmax = fmaxf(bcmax, __shfl_xor(bcmax, o));
-    }
-    // per-row inputs of all WM row blocks up front: one L2 round trip instead of one per block (the atomics of a block keep the
-    // compiler from hoisting the next block's loads)
-    int gt_[WM];
-    float sg_[WM], eps_[WM];
-#pragma unroll
-    for (int tr = 0; tr < WM; ++tr) {
-        const int rr = r0 + wr * (WM * 32) + tr * 32 + l31;
-        const bool row_ok = FULL || rr < a.nR;
-        gt_[tr] = -1; sg_[tr] = 0.0f; eps_[tr] = 0.0f;
-        if (counting && row_ok) {
-            gt_[tr] = a.gt_col[rr] - a.col0;
-            sg_[tr] = a.s_gt[rr];
-        }
-        if (banded && row_ok) {
-            gt_[tr] = a.gt_col[rr] - a.col0;
-            sg_[tr] = (float)a.s_gt64[rr];
-            eps_[tr] = a.band_r[rr] + bcmax;
-        }
-    }
+    const bool counting = EPI == EPI_SIM && a.count != nullptr;
 #pragma unroll
     for (int tr = 0; tr < WM; ++tr) {
         const int rbase = r0 + wr * (WM * 32) + tr * 32;
         const int rr = rbase + l31;
         const bool row_ok = FULL || rr < a.nR;
         int cnt = 0;
-        const int gt = gt_[tr];
-        const float sg = sg_[tr], eps = eps_[tr];
+        int gt = -1;
+        float sg = 0.0f;
+        if (counting && row_ok) {
+            gt = a.gt_col[rr] - a.col0;
+            sg = a.s_gt[rr];
+        }
         float rscl = a.scale;
         if (EPI == EPI_FC && a.row_scale && row_ok) rscl *= a.row_scale[rr];
 #pragma unroll
         for (int tc = 0; tc < WN; ++tc) {
-            if (EPI == EPI_SIM && banded) {
-                // Exact-rank count (laff_rank_prepare / laff_rank_resolve), one 32x32 block (16 values per lane) at a time: a score
-                // further than the proven error band from the exact ground-truth score is decided here; a pair inside the band is
-                // staged for the list that laff_rank_resolve re-scores exactly (fp64 on the fp32 embeddings).  The ground-truth pair
-                // is recognised by index: it takes the exact value in S, is never counted and never listed.  ONE scalar branch
-                // per block guards the rare part (a branch per quad cost ~2k cycles per wave in s_cmp / s_cbranch latency).
-                const int cb = cw0 + tc * 32;
-                float vv[4][4];
-                const unsigned long long gtm = __builtin_amdgcn_ballot_w64((unsigned)(gt - cb) < 32u);   // ground truth in this block
-                unsigned long long anym = gtm;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = acc[tr][tc][4 * q + e] * rscl;
-                        vv[q][e] = x;
-                        const float dlt = x - sg;
-                        const bool in = FULL || (row_ok && cb + 8 * q + 4 * hh + e < a.nC);
-                        cnt += (in && dlt > eps) ? 1 : 0;
-                        anym |= __builtin_amdgcn_ballot_w64(in && __builtin_fabsf(dlt) <= eps);   // the compare's lane mask, scalar OR
-                    }
-                if (anym != 0ull) {                                          // ~1/3 of the blocks
-                    // (1) this lane's in-band elements as a bit mask (branch-free; element i = 4 q + e <-> bit i)
-                    unsigned bits = 0u;
-#pragma unroll
-                    for (int i = 15; i >= 0; --i) {
-                        const bool in = FULL || (row_ok && cb + 8 * (i >> 2) + 4 * hh + (i & 3) < a.nC);
-                        bits = (bits << 1) | ((in && __builtin_fabsf(vv[i >> 2][i & 3] - sg) <= eps) ? 1u : 0u);
-                    }
-                    // (2) the ground-truth element: exact value into S, never counted, never listed
-                    if (gtm != 0ull) {                                       // scalar branch, ~1/10 of the blocks
-                        const int j = gt - cb;                               // column inside the block, if 0 <= j < 32
-                        const bool mine = (unsigned)j < 32u && ((j >> 2) & 1) == hh && row_ok && (FULL || gt < a.nC);   // (a column of the tile's padding is nobody's ground truth)
-                        const int gi = mine ? (j >> 3) * 4 + (j & 3) : -1;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const bool isg = i == gi;
-                            cnt -= (isg && vv[i >> 2][i & 3] - sg > eps) ? 1 : 0;
-                            vv[i >> 2][i & 3] = isg ? sg : vv[i >> 2][i & 3];
-                        }
-                        if (mine) bits &= ~(1u << gi);
-                    }
-                    // (3) stage the in-band pairs: one loop trip per flagged element of the busiest lane (usually one)
-                    while (__builtin_amdgcn_ballot_w64(bits != 0u) != 0ull) {
-                        if (bits != 0u) {
-                            const int i = __builtin_ctz(bits);
-                            bits &= bits - 1u;
-                            const unsigned cc = (unsigned)(cb + 8 * (i >> 2) + 4 * hh + (i & 3));
-                            const unsigned ls = atomicAdd(plist, 1u);        // LDS
-                            if (ls < (unsigned)PAIR_LCAP) {
-                                plist[4 + 2 * ls] = (unsigned)rr;
-                                plist[5 + 2 * ls] = cc;
-                            } else {                                         // staging list full: straight to the global list
-                                const size_t slot = ovf_base + atomicAdd(a.pairs, 1u);
-                                if (slot < a.pair_cap) {
-                                    a.pairs[4 + 2 * slot] = (unsigned)rr;
-                                    a.pairs[5 + 2 * slot] = cc;
-                                }
-                            }
-                        }
-                    }
-                }
-                if (a.out) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *(float4*)(slab + l31 * PITCH + tc * 32 + 8 * q + 4 * hh) = make_float4(vv[q][0], vv[q][1], vv[q][2], vv[q][3]);
-                }
-                continue;
-            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = tc * 32 + 8 * q + 4 * hh;          // column inside the wave's 64
@@ -349,7 +251,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
                 if (a.out) *(float4*)(slab + l31 * PITCH + cl) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
-        if (counting || banded) {
+        if (counting) {
             cnt += __shfl_xor(cnt, 32);
             if (hh == 0 && row_ok && cnt) atomicAdd(a.count + rr, cnt);
         }
@@ -382,30 +284,221 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
             __builtin_amdgcn_wave_barrier();            // slab is rewritten by the next 32-row block
         }
     }
-    if (banded) {
-        // Publish this tile's staged pairs WITHOUT a returning atomic (its ~1-2 us round trip at the very end of the tile is dead
-        // time for the whole CU): tile b owns the fixed segment [b * chunk, (b + 1) * chunk) of the list; unused slots are marked
-        // invalid.  Only a tile with more than `chunk` pairs appends the excess behind the segments with the global counter.
-        __syncthreads();
-        const unsigned n = min(plist[0], (unsigned)PAIR_LCAP);
-        const size_t seg = (size_t)blockIdx.x * chunk;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { a.pairs[2] = gridDim.x * chunk; a.pairs[3] = chunk; }
-        for (unsigned i = threadIdx.x; i < chunk; i += CF::THREADS) {
-            const bool have = i < n;
-            a.pairs[4 + 2 * (seg + i)] = have ? plist[4 + 2 * i] : 0xffffffffu;
-            a.pairs[5 + 2 * (seg + i)] = have ? plist[5 + 2 * i] : 0u;
-        }
-        if (n > chunk) {                                                    // block-uniform, rare
-            if (threadIdx.x == 0) plist[1] = atomicAdd(a.pairs, n - chunk);
-            __syncthreads();
-            const size_t base = ovf_base + plist[1];
-            for (unsigned i = chunk + threadIdx.x; i < n; i += CF::THREADS)
-                if (base + (i - chunk) < a.pair_cap) {
-                    a.pairs[4 + 2 * (base + (i - chunk))] = plist[4 + 2 * i];
-                    a.pairs[5 + 2 * (base + (i - chunk))] = plist[5 + 2 * i];
+}
+
+// ---- exact-rank ("banded") epilogue of the similarity GEMM ------------------------------------------------------------------
+// count[row] += #{col != gt : S > s_gt + band}; the pairs with |S - s_gt| <= band are staged for laff_rank_resolve (rank.hip), which
+// re-scores them exactly; S (optional) gets the exact ground-truth score at the ground-truth entry.  band = band_r[row] + the
+// maximum of band_c over the wave's 64 columns (computed once per 64-column block by laff_rank_prepare: one value per wave).
+//   * Everything this epilogue reads from global memory (gt_col, s_gt64, band_r of the lane's WM rows; the wave's column-block band)
+//     is fetched BEFORE the K loop (BandPre): an L2 round trip per 32-row block in front of the stores was ~1/4 of this epilogue.
+//   * The tests run in ACCUMULATOR units -- thresholds lo = (s_gt - band) / scale, hi = (s_gt + band) / scale per row -- and with
+//     vector registers only: two per-lane counters (x > hi, x >= lo), i.e. two compares and two add-with-carry per element and no
+//     VALU -> SGPR -> SALU hazard stalls; a 32x32 block holds a pair in the band iff the two counters moved apart: ONE lane-mask
+//     test per block guards the rare part.
+//   * The rare part turns the lane's in-band elements into a bit mask and compacts them wave-wide (ballot + mbcnt) into a
+//     wave-private LDS list: no LDS atomics, no workgroup barrier.
+//   * Each WAVE publishes its list into its own fixed segment of the global list (unused slots marked invalid): no global atomic.
+//     Only a wave with more pairs than its segment appends the excess behind the segments with the global counter.
+template <typename CF>
+struct BandPre {
+    int gt[CF::WM];           // ground-truth column of the lane's row in each 32-row block, relative to this shard (or < 0)
+    double sg[CF::WM];        // exact ground-truth score
+    float br[CF::WM];         // row part of the band
+    float bc;                 // column part of the band: maximum over the wave's WN*32 columns
+};
+
+// the kernel arguments the prefetch needs, read (and waited for) together with the tile's other arguments at the top of the tile:
+// left to the compiler they are fetched one s_load + wait at a time right in front of the loads that need them
+struct BandPtrs {
+    const int* gt_col; const double* s_gt64; const float* band_r; const float* band_c; int col0;
+};
+__device__ __forceinline__ BandPtrs band_ptrs(const GemmArgs& a) {
+    BandPtrs q{a.gt_col, a.s_gt64, a.band_r, a.band_c, a.col0};
+    asm volatile("" : "+s"(q.gt_col), "+s"(q.s_gt64), "+s"(q.band_r), "+s"(q.band_c), "+s"(q.col0));
+    return q;
+}
+
+template <typename CF>
+__device__ __forceinline__ void band_prefetch(const GemmArgs& a0, const BandPtrs& a, int r0, int c0, int wr, int wc, int lane, BandPre<CF>& p) {
+    constexpr int WM = CF::WM, WN = CF::WN;
+    const bool on = a.s_gt64 != nullptr && a0.count != nullptr;
+    p.bc = 0.0f;
+    const float* blk = a.band_c + a0.nC;                        // [ceil(nC / 64)] maxima of band_c over aligned 64-column blocks
+#pragma unroll
+    for (int i = 0; i < WN / 2; ++i) {
+        const int c = c0 + wc * (WN * 32) + i * 64;             // wave-uniform
+        if (on && c < a0.nC) p.bc = fmaxf(p.bc, blk[c >> 6]);
+    }
+#pragma unroll
+    for (int tr = 0; tr < WM; ++tr) {
+        const int rr = r0 + wr * (WM * 32) + tr * 32 + (lane & 31);
+        const bool ok = on && rr < a0.nR;
+        p.gt[tr] = ok ? a.gt_col[rr] - a.col0 : -1;
+        p.sg[tr] = ok ? a.s_gt64[rr] : 0.0;
+        p.br[tr] = ok ? a.band_r[rr] : 0.0f;
+    }
+}
+// keeps the prefetched values (and therefore their loads) in front of the K loop: a use the compiler cannot move
+template <typename CF>
+__device__ __forceinline__ void band_pin(BandPre<CF>& p) {
+    asm volatile("" : "+v"(p.bc));
+#pragma unroll
+    for (int tr = 0; tr < CF::WM; ++tr) asm volatile("" : "+v"(p.gt[tr]), "+v"(p.sg[tr]), "+v"(p.br[tr]));
+}
+
+template <bool FULL, typename CF>
+__device__ __forceinline__ void epilogue_banded(const GemmArgs& a, f32x16 (&acc)[CF::WM][CF::WN], int r0, int c0, int wr, int wc,
+                                                int wave, int lane, char* smem, const BandPre<CF>& pre) {
+    constexpr int WM = CF::WM, WN = CF::WN, PITCH = CF::PITCH, NWAVES = CF::THREADS / 64;
+    constexpr unsigned WCAP = PAIR_LCAP / NWAVES;                           // staged pairs per wave
+    const int l31 = lane & 31, hh = lane >> 5;
+    float* slab = (float*)smem + wave * (32 * PITCH);
+    const int cw0 = c0 + wc * (WN * 32);
+    unsigned* wl = (unsigned*)(smem + CF::SMEM) + 4 + wave * (2 * WCAP);    // this wave's staging list
+    const unsigned wchunk = pair_chunk(a.pair_cap, gridDim.x * NWAVES);     // slots of this wave's segment of the global list
+    const size_t ovf_base = (size_t)gridDim.x * NWAVES * wchunk;            // the overflow region starts behind the segments
+    unsigned wcount = 0;                                                    // wave-uniform: pairs staged so far
+#ifdef LAFF_GEMM_TRACE
+#define ETRACE(i) do { if (a.trace && threadIdx.x == 0) a.trace[(long)gridDim.x * 16 + (long)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ETRACE(i) do {} while (0)
+#endif
+    ETRACE(0);
+    const float inv_scale = 1.0f / a.scale;
+#pragma unroll
+    for (int tr = 0; tr < WM; ++tr) {
+        const int rbase = r0 + wr * (WM * 32) + tr * 32;
+        const int rr = rbase + l31;
+        const bool row_ok = FULL || rr < a.nR;
+        ETRACE(1 + tr);
+        const int gt = pre.gt[tr];
+        const float sg = (float)pre.sg[tr], eps = pre.br[tr] + pre.bc;
+        // accumulator-unit thresholds (the band's constant term carries the rounding of these two products)
+        const float lo = (sg - eps) * inv_scale, hi = (sg + eps) * inv_scale;
+        int c_hi = 0, c_lo = 0;                                             // #{x > hi}, #{x >= lo} over this lane's elements
+#pragma unroll
+        for (int tc = 0; tc < WN; ++tc) {
+            const int cb = cw0 + tc * 32;
+            const int before = c_lo - c_hi;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float x = acc[tr][tc][i];
+                if constexpr (FULL) {
+                    c_hi += (x > hi) ? 1 : 0;
+                    c_lo += (x >= lo) ? 1 : 0;
+                } else {
+                    const bool in = row_ok && cb + 8 * (i >> 2) + 4 * hh + (i & 3) < a.nC;
+                    c_hi += (in && x > hi) ? 1 : 0;
+                    c_lo += (in && x >= lo) ? 1 : 0;
                 }
+            }
+            const bool gt_here = (unsigned)(gt - cb) < 32u;                  // the ground-truth column is in this block
+            int gi = -1;                                                     // ... and this lane holds it, as element gi
+            if (__builtin_amdgcn_ballot_w64(gt_here || (c_lo - c_hi) != before) != 0ull) {      // ~1/3 of the blocks
+                unsigned bits = 0u;                                          // element i in the band [lo, hi] <-> bit i
+#pragma unroll
+                for (int i = 15; i >= 0; --i) {
+                    const float x = acc[tr][tc][i];
+                    const bool in = FULL || (row_ok && cb + 8 * (i >> 2) + 4 * hh + (i & 3) < a.nC);
+                    // med3(x, lo, hi) == x  <=>  lo <= x <= hi (false for NaN): one compare, no scalar mask arithmetic
+                    bits = bits + bits + ((in && __builtin_amdgcn_fmed3f(x, lo, hi) == x) ? 1u : 0u);
+                }
+                if (__builtin_amdgcn_ballot_w64(gt_here) != 0ull) {          // scalar branch, ~1/10 of the blocks
+                    const int j = gt - cb;
+                    const bool mine = gt_here && ((j >> 2) & 1) == hh && row_ok && (FULL || gt < a.nC);
+                    gi = mine ? (j >> 3) * 4 + (j & 3) : -1;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) c_hi -= (i == gi && acc[tr][tc][i] > hi) ? 1 : 0;    // never counted
+                    if (mine) bits &= ~(1u << gi);                           // never listed
+                }
+                unsigned long long m;
+                while ((m = __builtin_amdgcn_ballot_w64(bits != 0u)) != 0ull) {     // one trip per pair of the busiest lane
+                    if (bits != 0u) {
+                        const int i = __builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        const unsigned cc = (unsigned)(cb + 8 * (i >> 2) + 4 * hh + (i & 3));
+                        const unsigned slot = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (slot < WCAP) {
+                            wl[2 * slot] = (unsigned)rr;
+                            wl[2 * slot + 1] = cc;
+                        } else {                                             // staging list full: straight to the global list
+                            const size_t g = ovf_base + atomicAdd(a.pairs, 1u);
+                            if (g < a.pair_cap) {
+                                a.pairs[4 + 2 * g] = (unsigned)rr;
+                                a.pairs[5 + 2 * g] = cc;
+                            }
+                        }
+                    }
+                    wcount += (unsigned)__builtin_popcountll(m);
+                }
+            }
+            if (a.out) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[tr][tc][4 * q + e] * a.scale;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (4 * q + e == gi) ? sg : v[e];     // the exact score at the ground-truth entry
+                    *(float4*)(slab + l31 * PITCH + tc * 32 + 8 * q + 4 * hh) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        int cnt = c_hi + __shfl_xor(c_hi, 32);
+        if (hh == 0 && row_ok && cnt) atomicAdd(a.count + rr, cnt);
+        if (a.out) {
+            __builtin_amdgcn_wave_barrier();
+            constexpr int LPR = WN * 8, RPI = 64 / LPR;      // lanes per slab row, rows per store instruction
+            const int col4 = (lane % LPR) * 4;
+            const int gc = cw0 + col4;
+#pragma unroll
+            for (int j = 0; j < 32 / RPI; ++j) {
+                const int row = lane / LPR + RPI * j;
+                const float4 v = *(const float4*)(slab + row * PITCH + col4);
+                const int gr = rbase + row;
+                float* o = a.out + (long)gr * a.ldo + gc;
+                if constexpr (FULL) {
+                    __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), (f32x4*)o);
+                } else if (gr < a.nR) {
+                    const bool vec_ok = ((a.ldo & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0);
+                    if (vec_ok && gc + 3 < a.nC) {
+                        *(float4*)o = v;
+                    } else {
+                        const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (gc + e < a.nC) o[e] = t[e];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();            // slab is rewritten by the next 32-row block
         }
     }
+    ETRACE(5);
+    // publish: this wave's segment [w * wchunk, (w + 1) * wchunk) of the global list, valid pairs first, the rest marked invalid
+    wcount = __builtin_amdgcn_readfirstlane(wcount);
+    const unsigned n = min(wcount, WCAP);
+    const size_t seg = ((size_t)blockIdx.x * NWAVES + wave) * wchunk;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.pairs[2] = gridDim.x * NWAVES * wchunk; a.pairs[3] = wchunk; }
+    for (unsigned i = lane; i < wchunk; i += 64) {
+        const bool have = i < n;
+        a.pairs[4 + 2 * (seg + i)] = have ? wl[2 * i] : 0xffffffffu;
+        a.pairs[5 + 2 * (seg + i)] = have ? wl[2 * i + 1] : 0u;
+    }
+    ETRACE(6);
+    if (n > wchunk) {                                                       // wave-uniform, rare
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(a.pairs, n - wchunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (unsigned i = wchunk + lane; i < n; i += 64)
+            if (ovf_base + base + (i - wchunk) < a.pair_cap) {
+                a.pairs[4 + 2 * (ovf_base + base + (i - wchunk))] = wl[2 * i];
+                a.pairs[5 + 2 * (ovf_base + base + (i - wchunk))] = wl[2 * i + 1];
+            }
+    }
+    ETRACE(7);
+#undef ETRACE
 }
 
 // ---- one output tile ----------------------------------------------------------------------------------------------
@@ -427,6 +520,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
     constexpr int ESZ = ModeTraits<MODE>::ESZ;
     constexpr int WM = CF::WM, WN = CF::WN, THREADS = CF::THREADS;
     constexpr bool GLDS = STG != 0;
+    BandPtrs bptr{};
+    if constexpr (EPI == EPI_SIM) bptr = band_ptrs(a);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -511,16 +606,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
 #pragma unroll
     for (int ks = 0; ks < ROWB / 32; ++ks) xk[ks] = (unsigned)(((2 * ks + hh) ^ ((l31 >> 1) & 7)) * 16);
 
-    // column part of the error band of the banded count (EPI_SIM): fetched here, used after the K loop
-    float bc_pre[WN / 2];
-#pragma unroll
-    for (int i = 0; i < WN / 2; ++i) {
-        bc_pre[i] = 0.0f;
-        if constexpr (EPI == EPI_SIM) {
-            const int c = c0 + wc * (WN * 32) + i * 64 + lane;
-            if (a.s_gt64 && a.count && c < a.nC) bc_pre[i] = a.band_c[c];
-        }
-    }
+    // inputs of the banded count (EPI_SIM): fetched here, used after the K loop
+    BandPre<CF> pre;
+    const bool banded = EPI == EPI_SIM && a.s_gt64 != nullptr && a.count != nullptr;
+    if constexpr (EPI == EPI_SIM && STG != 2) band_prefetch<CF>(a, bptr, r0, c0, wr, wc, lane, pre);
     TRACE(1);
     if constexpr (STG == 2) {
         // ---- software-pipelined K loop (fast staging) ---------------------------------------------------------------
@@ -598,7 +687,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         static_assert(NSUB % 2 == 0, "fragment buffer parity must repeat every K-step");
         // prologue: stage 0 landed and visible, stage 1 in flight, fragments of (K-step 0, sub-step 0) in flight
         stage_next(0);
+        // the banded epilogue's inputs ride under the first stage's load latency (their address arithmetic too)
+        if constexpr (EPI == EPI_SIM) band_prefetch<CF>(a, bptr, r0, c0, wr, wc, lane, pre);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (EPI == EPI_SIM) band_pin<CF>(pre);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         TRACE(2);
@@ -720,8 +812,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
     TRACE(5);
     const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
                       ((((uintptr_t)a.out) & 15) == 0);
-    if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, bc_pre);
-    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, bc_pre);
+    if (EPI == EPI_SIM && banded) {
+        if (full) epilogue_banded<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, pre);
+        else epilogue_banded<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, pre);
+    } else if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     TRACE(6);
 #undef TRACE
 }
@@ -755,6 +850,8 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     static_assert(MODE == GEMM_F16 || MODE == GEMM_BF16, "the split product runs on the 16-bit matrix pipe");
     using CF = CfgX3;
     constexpr int WM = CF::WM, WN = CF::WN, THREADS = CF::THREADS, RB = CF::ROWB, CPR = CF::CPR;
+    BandPtrs bptr{};
+    if constexpr (EPI == EPI_SIM) bptr = band_ptrs(a);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -902,19 +999,13 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     using I4 = std::integral_constant<int, 4>;
     using I6 = std::integral_constant<int, 6>;
 
-    float bc_pre[WN / 2];
-#pragma unroll
-    for (int i = 0; i < WN / 2; ++i) {
-        bc_pre[i] = 0.0f;
-        if constexpr (EPI == EPI_SIM) {
-            const int c = c0 + wc * (WN * 32) + i * 64 + lane;
-            if (a.s_gt64 && a.count && c < a.nC) bc_pre[i] = a.band_c[c];
-        }
-    }
+    BandPre<CF> pre;
+    const bool banded = EPI == EPI_SIM && a.s_gt64 != nullptr && a.count != nullptr;
     // prologue: stage 0 landed and visible, stage 1 in flight, operands of the first B group (C_lo, R_hi of slice 0) in flight
     fill_begin(0, 0);
     if constexpr (RF32) xload();
     fill_all();
+    if constexpr (EPI == EPI_SIM) band_prefetch<CF>(a, bptr, r0, c0, wr, wc, lane, pre);   // under the first stage's load latency
     if constexpr (RF32) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[1][0]), "+v"(xs[1][1])::"memory");
         xconvert();
@@ -922,6 +1013,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if constexpr (EPI == EPI_SIM) band_pin<CF>(pre);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (nkt > 1) {
@@ -992,8 +1084,11 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     __syncthreads();                                   // every wave is done reading the operand ring
     const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
                       ((((uintptr_t)a.out) & 15) == 0);
-    if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, bc_pre);
-    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, bc_pre);
+    if (EPI == EPI_SIM && banded) {
+        if (full) epilogue_banded<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, pre);
+        else epilogue_banded<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, pre);
+    } else if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
 }
 
 template <int MODE>
@@ -1002,7 +1097,6 @@ __global__ __launch_bounds__(CfgX3::THREADS, CfgX3::WPS) void gemm_nt_x3_kernel(
     const int tiles_r = (a.nR + CfgX3::TR - 1) / CfgX3::TR, tiles_c = (a.nC + CfgX3::TC - 1) / CfgX3::TC;
     int r0, c0;
     tile_origin<CfgX3>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), r0, c0);
-    if (threadIdx.x == 0) *(unsigned*)(smem + CfgX3::SMEM) = 0u;            // pair staging counter (ordered by the K loop's barriers)
     gemm_tile_x3<MODE, EPI_SIM>(a, r0, c0, smem);
 }
 
@@ -1046,7 +1140,6 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_kernel(GemmArgs 
     const int tiles_r = (a.nR + CF::TR - 1) / CF::TR, tiles_c = (a.nC + CF::TC - 1) / CF::TC;
     int r0, c0;
     tile_origin<CF>(a, xcd_remap(blockIdx.x, tiles_r * tiles_c), r0, c0);
-    if (threadIdx.x == 0) *(unsigned*)(smem + CF::SMEM) = 0u;               // pair staging counter (ordered by the K loop's barriers)
     gemm_tile<MODE, STG, CF, EPI_SIM>(a, r0, c0, smem);
 }
 

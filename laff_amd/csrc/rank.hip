@@ -164,11 +164,11 @@ hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K
 // (the infinitely precise value of what loss.cosine_sim computes in fp32; products of fp32 values are exact in fp64).
 //   * laff_rank_prepare : s_gt64[t] = exact(t, gt(t)); for every operand row the MEASURED quantisation error
 //                         q = |operand/prescale - normalised embedding|_2, turned into band halves
-//                             band_t[t] = q_t / sqrt(H) * (1 + u) + K * 2^-23 + 2^-22,   band_v[v] = q_v / sqrt(H)
+//                             band_t[t] = q_t / sqrt(H) * (1 + u) + K * 2^-23 + 2^-20,   band_v[v] = q_v / sqrt(H)
 //                         so that |approx(t,v) - exact(t,v)| <= band_t[t] + band_v[v]   (Cauchy-Schwarz on
 //                         dt.v + t.dv + dt.dv with |t^| = |v^| = sqrt(H); u = unit roundoff of the operand format bounds the
 //                         cross term; K * 2^-23 covers the fp32 accumulation of K exact products under round-to-nearest or
-//                         truncation, 2^-22 the final scaling and the fp32 copy of s_gt64);
+//                         truncation, 2^-20 the final scaling, the fp32 copy of s_gt64 and the rounding of the epilogue's thresholds);
 //   * the GEMM epilogue decides every pair outside the band and lists the pairs inside it (gemm_nt.hip);
 //   * laff_rank_resolve  re-scores the listed pairs with exact() and fixes count / S.
 // Rows / pairs are handled by GROUPS OF 16 LANES (4 per wavefront): lane sl of a group owns the float4 columns {64 j + 4 sl}.
@@ -270,7 +270,8 @@ __device__ __forceinline__ float row_pass(const float* __restrict__ e, const voi
     return (float)sqrt(q2);
 }
 
-constexpr int PREP_ROWS = 256 / RG;            // rows per 256-thread block
+constexpr int PREP_ROWS = 256 / RG;            // text rows per 256-thread block
+constexpr int PREP_VROWS = 64;                 // video rows per block: one aligned 64-column group of the GEMM (one band value per wave)
 
 template <int PREC>
 __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restrict__ Et, const float* __restrict__ Ev,
@@ -279,13 +280,14 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
                                                            int col0, double* __restrict__ s_gt64, float* __restrict__ band_t,
                                                            float* __restrict__ band_v, int* __restrict__ zero_count,
                                                            unsigned* __restrict__ pairs) {
+    __shared__ float blkmax[PREP_ROWS];
     const int sl = threadIdx.x & (RG - 1), grp = threadIdx.x / RG;
     const long K = (long)H * d;
-    const long tblocks = ((long)Nt + PREP_ROWS - 1) / PREP_ROWS;
+    const long vblocks = ((long)Nv + PREP_VROWS - 1) / PREP_VROWS;       // the (longer) video blocks come first in the grid
     if (blockIdx.x == 0 && threadIdx.x < 4 && pairs) pairs[threadIdx.x] = 0u;       // pair counter + overflow flag
     const float rsqrt_h = 1.0f / sqrtf((float)H);
-    if ((long)blockIdx.x < tblocks) {
-        const long t0 = (long)blockIdx.x * PREP_ROWS + grp;
+    if ((long)blockIdx.x >= vblocks) {
+        const long t0 = ((long)blockIdx.x - vblocks) * PREP_ROWS + grp;
         const bool ok = t0 < Nt;
         const long t = ok ? t0 : Nt - 1;                       // idle groups shadow the last row (shuffles stay convergent)
         if (ok && zero_count && sl == 0) zero_count[t] = 0;
@@ -305,24 +307,40 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
             band_t[t] = q * rsqrt_h * (1.0f + unit) * 1.0001f + c_acc;
         }
     } else {
-        const long v0 = ((long)blockIdx.x - tblocks) * PREP_ROWS + grp;
-        const bool ok = v0 < Nv;
-        const long v = ok ? v0 : Nv - 1;
-        const float q = row_pass<PREC, false>(Ev + v * K, V, v, Nv, H, d, (double)inv_prescale, sl, nullptr, nullptr);
-        if (ok && sl == 0) band_v[v] = q * rsqrt_h * 1.0001f;
+        // video rows [64 b, 64 b + 64): per-row band_v and, behind the Nv per-row values, the maximum of the block (what a wave of the
+        // GEMM epilogue uses for its 64 columns)
+        const long vb = (long)blockIdx.x;
+        float mx = 0.0f;
+        for (int k = 0; k < PREP_VROWS / PREP_ROWS; ++k) {
+            const long v0 = vb * PREP_VROWS + k * PREP_ROWS + grp;
+            const bool ok = v0 < Nv;
+            const long v = ok ? v0 : Nv - 1;
+            const float q = row_pass<PREC, false>(Ev + v * K, V, v, Nv, H, d, (double)inv_prescale, sl, nullptr, nullptr);
+            const float b = q * rsqrt_h * 1.0001f;
+            if (ok && sl == 0) band_v[v] = b;
+            if (ok) mx = fmaxf(mx, b);
+        }
+        if (sl == 0) blkmax[grp] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = 0.0f;
+            for (int i = 0; i < PREP_ROWS; ++i) m = fmaxf(m, blkmax[i]);
+            band_v[Nv + vb] = m;
+        }
     }
 }
 
 hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
                                int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t,
                                float* band_v, int* zero_count, unsigned* pairs, hipStream_t st) {
-    const long grid = ((long)Nt + PREP_ROWS - 1) / PREP_ROWS + ((long)Nv + PREP_ROWS - 1) / PREP_ROWS;
+    const long grid = ((long)Nt + PREP_ROWS - 1) / PREP_ROWS + ((long)Nv + PREP_VROWS - 1) / PREP_VROWS;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
     const float inv = 1.0f / prescale;
     // fp32 accumulation of the exact products: K terms (3K for a hi/lo split, plus its dropped lo*lo term <= 2^-22), 2^-23 each
-    // (covers round-to-nearest and truncating accumulators), + 2^-22 for the final scaling and the fp32 copy of s_gt64
+    // (covers round-to-nearest and truncating accumulators), + 2^-20 for the fp32 copy of s_gt64, the scaling and the rounding of the
+    // accumulator-unit thresholds the GEMM epilogue compares against
     const bool x3 = precision == LAFF_PREC_FP16X3 || precision == LAFF_PREC_BF16X3;
-    const float c_acc = (float)((double)H * d * (x3 ? 3.0 : 1.0) * 1.1920929e-7 + 2.3841858e-7 * (x3 ? 2.0 : 1.0));
+    const float c_acc = (float)((double)H * d * (x3 ? 3.0 : 1.0) * 1.1920929e-7 + 9.5367432e-7 + (x3 ? 2.3841858e-7 : 0.0));
 #define LAFF_PREP(P, U)                                                                                                          \
     hipLaunchKernelGGL((rank_prepare_kernel<P>), dim3((unsigned)grid), dim3(256), 0, st, Et, Ev, T, V, Nt, Nv, H, d, inv, U, c_acc, gt_col, \
                        col0, s_gt64, band_t, band_v, zero_count, pairs)
@@ -339,9 +357,9 @@ hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, 
 }
 
 // one 16-lane group per listed pair.  The list (written by the banded GEMM epilogue): header {n_overflow, overflow flag, A, chunk},
-// then A = tiles * chunk slots in per-tile segments (valid pairs first, the rest marked row = 0xffffffff), then n_overflow pairs
-// appended with the counter.  A wavefront takes a segment (4 pairs at a time, until the first invalid slot), then a share of the
-// overflow region.  count[row] += 1 when the exact score beats the exact ground-truth score; S (optional) takes the fp32 value of the
+// then A slots in per-wavefront segments of `chunk` slots (valid pairs first, the rest marked row = 0xffffffff), then n_overflow
+// pairs appended with the counter.  A 16-lane group walks a segment until the first invalid slot; the overflow region is shared out
+// four pairs per wavefront at a time.  count[row] += 1 when the exact score beats the exact ground-truth score; S (optional) takes the fp32 value of the
 // exact score, nudged by one ulp where rounding to fp32 would hide a strict inequality, so that ranks recounted from S
 // (laff_rank_count) equal the ranks produced here.  More pairs than the list holds: overflow flag + count[0] poisoned (rank < 1 trips
 // the error flag of laff_rank_metrics*).
@@ -349,9 +367,9 @@ __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restri
                                                            const double* __restrict__ s_gt64, int* __restrict__ count,
                                                            float* __restrict__ S, long lds, unsigned* __restrict__ pairs,
                                                            unsigned pair_cap) {
-    const int sl = threadIdx.x & (RG - 1), sub = (threadIdx.x / RG) & 3;
+    const int sl = threadIdx.x & (RG - 1);
     const long K = (long)H * d;
-    const unsigned n_over = pairs[0], regA = pairs[2], chunk = pairs[3];
+    const unsigned n_over = pairs[0], regA = pairs[2];
     const unsigned long long room = pair_cap > regA ? pair_cap - regA : 0u;
     if (n_over > room) {
         if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[1] = 1u; count[0] = -0x40000000; }
@@ -370,24 +388,50 @@ __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restri
             }
         }
     };
-    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
-    const unsigned ntiles = chunk ? regA / chunk : 0u;
-    for (unsigned b = wave; b < ntiles; b += nwaves) {                       // wave-uniform loops: the shuffles stay convergent
-        const size_t seg = (size_t)b * chunk;
-        for (unsigned i0 = 0; i0 < chunk; i0 += 4) {
-            const unsigned r = pairs[4 + 2 * (seg + i0 + sub)], c = pairs[5 + 2 * (seg + i0 + sub)];
-            const bool ok = r != 0xffffffffu;
-            if (__builtin_amdgcn_ballot_w64(ok) == 0ull) break;              // valid pairs come first in a segment
-            one(ok ? r : 0u, ok ? c : 0u, ok);
+    // Two steps per wavefront, so that the expensive part always runs four pairs wide:
+    //   scan : its four 16-lane groups read blocks of 4 consecutive slots (segments are multiples of 4 slots with their valid pairs
+    //          first; the overflow region follows the segments) and queue the valid pairs in LDS (ballot + mbcnt, wave-private);
+    //   drain: the queue is re-scored four pairs at a time, one per group.
+    constexpr unsigned QCAP = 512;
+    __shared__ unsigned queue[4][QCAP][2];
+    const unsigned wv = threadIdx.x >> 6, sub = (threadIdx.x / RG) & 3u, lane = threadIdx.x & 63u;
+    const unsigned n = (unsigned)(n_over < room ? n_over : room);
+    const unsigned long long total = (unsigned long long)regA + n;
+    const unsigned group = (blockIdx.x * 256u + threadIdx.x) / RG, ngroups = gridDim.x * (256u / RG);
+    unsigned qn = 0;                                                         // wave-uniform
+    auto drain = [&]() {
+        for (unsigned i = 0; i < qn; i += 4) {
+            const unsigned j = i + sub;
+            const bool ok = j < qn;
+            const unsigned k = ok ? j : qn - 1;
+            one(queue[wv][k][0], queue[wv][k][1], ok);
+        }
+        qn = 0;
+    };
+    const unsigned long long trips = (total + 4ull * ngroups - 1) / (4ull * ngroups);
+    for (unsigned long long it = 0; it < trips; ++it) {                      // wave-uniform trip count
+        if (qn > QCAP - 16) drain();
+        const unsigned long long s0 = 4ull * (it * ngroups + group);
+        uint4 p0 = make_uint4(0xffffffffu, 0, 0xffffffffu, 0), p1 = p0;
+        if (s0 < total) {
+            p0 = *(const uint4*)(pairs + 4 + 2 * s0);                        // {r0, c0, r1, c1}
+            if (p0.x != 0xffffffffu && s0 + 2 < total) p1 = *(const uint4*)(pairs + 4 + 2 * s0 + 4);   // {r2, c2, r3, c3}
+        }
+        const unsigned rs[4] = {p0.x, p0.z, p1.x, p1.z}, cs[4] = {p0.y, p0.w, p1.y, p1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool v = sl == 0 && s0 + k < total && rs[k] != 0xffffffffu;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
+            if (v) {
+                const unsigned at = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                queue[wv][at][0] = rs[k];
+                queue[wv][at][1] = cs[k];
+            }
+            qn += (unsigned)__builtin_popcountll(m);
         }
     }
-    const unsigned n = (unsigned)(n_over < room ? n_over : room);
-    for (unsigned i0 = wave * 4u; i0 < n; i0 += nwaves * 4u) {
-        const unsigned i = i0 + sub;
-        const bool ok = i < n;
-        const size_t j = (size_t)regA + (ok ? i : n - 1);
-        one(pairs[4 + 2 * j], pairs[5 + 2 * j], ok);
-    }
+    (void)lane;
+    drain();
 }
 
 hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64, int* count,

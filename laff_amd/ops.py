@@ -526,7 +526,7 @@ def _emb3(E, name):
 
 
 def default_pair_cap(Nt):
-    return max(1 << 20, 32 * int(Nt))
+    return max(1 << 20, 64 * int(Nt))
 
 
 def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None):
@@ -547,7 +547,7 @@ def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None):
     cap = int(pair_cap) if pair_cap is not None else default_pair_cap(Nt)
     s_gt64 = torch.empty((Nt,), device=dev, dtype=torch.float64)
     band_t = torch.empty((max(Nt, 1),), device=dev, dtype=torch.float32)
-    band_v = torch.empty((max(Nv, 4),), device=dev, dtype=torch.float32)
+    band_v = torch.empty((Nv + (Nv + 63) // 64 + 4,), device=dev, dtype=torch.float32)     # per column, then per 64-column block
     count = torch.empty((Nt,), device=dev, dtype=torch.int32)
     pairs = torch.empty((4 + 2 * cap,), device=dev, dtype=torch.int32)
     lib, h = _context(dev)
