@@ -185,6 +185,7 @@ def main():
                     help="N > 1 decomposition: 'video' (BASELINE.json: video-row shards, all-gather of the text embeddings, two small "
                          "all-reduces), 'text' (text-row shards, all-gather of the video embeddings, no all-reduce) or 'auto' = the one "
                          "that gathers fewer rows (laff_amd.dist.choose_sharding)")
+    ap.add_argument('--two-streams', action='store_true', help='single GPU: alternate the two captured steps between two streams')
     ap.add_argument('--no-extra-modes', action='store_true', help='skip the sustained loop and the count-only mode (profiling runs)')
     ap.add_argument('--sustain-seconds', type=float, default=2.0, help='extra untimed-by-the-driver loop reporting the sustained rate')
     ap.add_argument('--force-dist', action='store_true', help='run the N > 1 code path (collectives included) on a 1-rank group')
@@ -273,7 +274,7 @@ def main():
     #   N > 1      : one captured graph per LOCAL phase (laff_amd.dist.GraphRunner), the three RCCL collectives eager
     #                between them -- nothing RCCL-related is ever captured;
     #   --no-graph : eager launches.
-    graph, graphs, runner, state = None, [], None, {}
+    graph, graphs, runner, state, side = None, [], None, {}, None
     for _ in range(max(1, args.warmup)):
         res = step(False)
     torch.cuda.synchronize()
@@ -298,6 +299,10 @@ def main():
                     torch.cuda.synchronize()
                     graphs.append(gph)
                 graph = graphs[0]
+                if args.two_streams:
+                    # steps k and k+1 on two streams: the latency-bound tail of a step (prepare / resolve / metrics, the sparse last
+                    # round of a GEMM) runs beside the next step's first kernels; the two captures share nothing but read-only inputs
+                    side = [torch.cuda.Stream(), torch.cuda.Stream()]
         except Exception as e:  # noqa: BLE001
             print('warning: HIP graph capture failed (%s); timing eager launches' % e, file=sys.stderr)
             graph, runner = None, None
@@ -327,11 +332,16 @@ def main():
         events = [torch.cuda.Event(), torch.cuda.Event()]
         seen = []
         for k in range(args.steps):
-            if graph is not None:
+            if graph is not None and side is not None:
+                with torch.cuda.stream(side[k % 2]):
+                    graphs[k % 2].replay()
+                    events[k % 2].record()
+            elif graph is not None:
                 graphs[k % 2].replay()
+                events[k % 2].record()
             else:
                 res = step(False, async_metrics=True, runner=runner, state=state, slot=k % 2)
-            events[k % 2].record()
+                events[k % 2].record()
             if k:
                 events[(k - 1) % 2].synchronize()
                 check_metrics_flag(pins[(k - 1) % 2])

@@ -308,35 +308,44 @@ struct BandPre {
     float bc;                 // column part of the band: maximum over the wave's WN*32 columns
 };
 
-// the kernel arguments the prefetch needs, read (and waited for) together with the tile's other arguments at the top of the tile:
-// left to the compiler they are fetched one s_load + wait at a time right in front of the loads that need them
+// The kernel arguments the prefetch needs, read ONCE at the top of the tile and pinned in scalar registers: left to the compiler they
+// are re-fetched (s_load + lgkmcnt(0) wait, which also drains the hand-counted LDS reads) right where the prefetch sits in the K
+// loop: ~1.3k cycles per tile.  They are pinned as integers and turned back into GLOBAL pointers at the use: laundering the
+// pointers themselves strips their address space and the loads become FLAT loads, which count in lgkmcnt as well.
+typedef const int __attribute__((address_space(1)))* gptr_i32;
+typedef const double __attribute__((address_space(1)))* gptr_f64;
+typedef const float __attribute__((address_space(1)))* gptr_f32;
 struct BandPtrs {
-    const int* gt_col; const double* s_gt64; const float* band_r; const float* band_c; int col0;
+    unsigned long long gt_col, s_gt64, band_r, band_c;
+    int col0, nR, nC, on;
 };
 __device__ __forceinline__ BandPtrs band_ptrs(const GemmArgs& a) {
-    BandPtrs q{a.gt_col, a.s_gt64, a.band_r, a.band_c, a.col0};
-    asm volatile("" : "+s"(q.gt_col), "+s"(q.s_gt64), "+s"(q.band_r), "+s"(q.band_c), "+s"(q.col0));
+    BandPtrs q{uniform64((unsigned long long)a.gt_col), uniform64((unsigned long long)a.s_gt64), uniform64((unsigned long long)a.band_r),
+               uniform64((unsigned long long)a.band_c), __builtin_amdgcn_readfirstlane(a.col0), __builtin_amdgcn_readfirstlane(a.nR),
+               __builtin_amdgcn_readfirstlane(a.nC),
+               __builtin_amdgcn_readfirstlane((a.s_gt64 != nullptr && a.count != nullptr) ? 1 : 0)};
+    asm volatile("" : "+s"(q.gt_col), "+s"(q.s_gt64), "+s"(q.band_r), "+s"(q.band_c), "+s"(q.col0), "+s"(q.nR), "+s"(q.nC), "+s"(q.on));
     return q;
 }
 
 template <typename CF>
-__device__ __forceinline__ void band_prefetch(const GemmArgs& a0, const BandPtrs& a, int r0, int c0, int wr, int wc, int lane, BandPre<CF>& p) {
+__device__ __forceinline__ void band_prefetch(const BandPtrs& a, int r0, int c0, int wr, int wc, int lane, BandPre<CF>& p) {
     constexpr int WM = CF::WM, WN = CF::WN;
-    const bool on = a.s_gt64 != nullptr && a0.count != nullptr;
+    const bool on = a.on != 0;
     p.bc = 0.0f;
-    const float* blk = a.band_c + a0.nC;                        // [ceil(nC / 64)] maxima of band_c over aligned 64-column blocks
+    gptr_f32 blk = (gptr_f32)a.band_c + a.nC;                   // [ceil(nC / 64)] maxima of band_c over aligned 64-column blocks
 #pragma unroll
     for (int i = 0; i < WN / 2; ++i) {
         const int c = c0 + wc * (WN * 32) + i * 64;             // wave-uniform
-        if (on && c < a0.nC) p.bc = fmaxf(p.bc, blk[c >> 6]);
+        if (on && c < a.nC) p.bc = fmaxf(p.bc, blk[c >> 6]);
     }
 #pragma unroll
     for (int tr = 0; tr < WM; ++tr) {
         const int rr = r0 + wr * (WM * 32) + tr * 32 + (lane & 31);
-        const bool ok = on && rr < a0.nR;
-        p.gt[tr] = ok ? a.gt_col[rr] - a.col0 : -1;
-        p.sg[tr] = ok ? a.s_gt64[rr] : 0.0;
-        p.br[tr] = ok ? a.band_r[rr] : 0.0f;
+        const bool ok = on && rr < a.nR;
+        p.gt[tr] = ok ? ((gptr_i32)a.gt_col)[rr] - a.col0 : -1;
+        p.sg[tr] = ok ? ((gptr_f64)a.s_gt64)[rr] : 0.0;
+        p.br[tr] = ok ? ((gptr_f32)a.band_r)[rr] : 0.0f;
     }
 }
 // keeps the prefetched values (and therefore their loads) in front of the K loop: a use the compiler cannot move
@@ -609,7 +618,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
     // inputs of the banded count (EPI_SIM): fetched here, used after the K loop
     BandPre<CF> pre;
     const bool banded = EPI == EPI_SIM && a.s_gt64 != nullptr && a.count != nullptr;
-    if constexpr (EPI == EPI_SIM && STG != 2) band_prefetch<CF>(a, bptr, r0, c0, wr, wc, lane, pre);
+    if constexpr (EPI == EPI_SIM && STG != 2) band_prefetch<CF>(bptr, r0, c0, wr, wc, lane, pre);
     TRACE(1);
     if constexpr (STG == 2) {
         // ---- software-pipelined K loop (fast staging) ---------------------------------------------------------------
@@ -687,10 +696,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         static_assert(NSUB % 2 == 0, "fragment buffer parity must repeat every K-step");
         // prologue: stage 0 landed and visible, stage 1 in flight, fragments of (K-step 0, sub-step 0) in flight
         stage_next(0);
-        // the banded epilogue's inputs ride under the first stage's load latency (their address arithmetic too)
-        if constexpr (EPI == EPI_SIM) band_prefetch<CF>(a, bptr, r0, c0, wr, wc, lane, pre);
+        // The banded epilogue's inputs are requested behind the first stage's DMA, under its latency.  (Measured alternatives, all
+        // within noise of this one: right behind the first barrier -- +2.3k cycles on K-step 0; behind the last refill piece of
+        // K-step 1 with a counted `vmcnt(3 WM)` at that step's barrier so that they stay in flight for a whole K-step -- the next
+        // barrier still waits ~1.7k cycles for them: under the DMA stream these 13 requests take ~4k cycles to return.)
+        if constexpr (EPI == EPI_SIM) band_prefetch<CF>(bptr, r0, c0, wr, wc, lane, pre);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (EPI == EPI_SIM) band_pin<CF>(pre);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         TRACE(2);
@@ -755,6 +766,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
             mfmas((NSUB - 1) & 1, IC0{}, std::integral_constant<int, NP0>{}, fill_on);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (EPI == EPI_SIM) band_pin<CF>(pre);
 #ifdef LAFF_GEMM_TRACE
         if (a.trace && tid == 0) {
             unsigned long long* t2 = a.trace + (long)gridDim.x * 8 + (long)blockIdx.x * 8;
@@ -1005,7 +1017,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     fill_begin(0, 0);
     if constexpr (RF32) xload();
     fill_all();
-    if constexpr (EPI == EPI_SIM) band_prefetch<CF>(a, bptr, r0, c0, wr, wc, lane, pre);   // under the first stage's load latency
+    if constexpr (EPI == EPI_SIM) band_prefetch<CF>(bptr, r0, c0, wr, wc, lane, pre);   // under the first stage's load latency
     if constexpr (RF32) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[1][0]), "+v"(xs[1][1])::"memory");
         xconvert();
@@ -1013,7 +1025,6 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if constexpr (EPI == EPI_SIM) band_pin<CF>(pre);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (nkt > 1) {
@@ -1023,6 +1034,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     }
     rd_fc(1, 0, 0, 1);
     rd_fr(1, 0, 0, 0);
+
     for (int kt = 0; kt < nkt; ++kt) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1081,6 +1093,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
         }
     }
 
+    if constexpr (EPI == EPI_SIM) band_pin<CF>(pre);
     __syncthreads();                                   // every wave is done reading the operand ring
     const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
                       ((((uintptr_t)a.out) & 15) == 0);
