@@ -193,6 +193,12 @@ def main():
     ap.add_argument('--seed', type=int, default=1237)
     args = ap.parse_args()
 
+    # stdout carries ONE line (the JSON): native libraries print banners to fd 1 (RCCL's version block at communicator teardown), so
+    # fd 1 is pointed at stderr for the whole run and the line is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -571,7 +577,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             sn, sv = (Nt, Nv) if float(Nt) * Nv <= 4.0e8 else (40000, 10000)       # ~10-20 s of host work
             line['cpu_baseline'] = cpu_baseline(args.workload, sn, sv, heads, d, args.seed, spec)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
     # orderly teardown: captured graphs and their private pools go away while the HIP runtime is still up
     import gc
     graph = graphs = runner = state = res = None
