@@ -695,12 +695,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         using IC0 = std::integral_constant<int, 0>;
         static_assert(NSUB % 2 == 0, "fragment buffer parity must repeat every K-step");
         // prologue: stage 0 landed and visible, stage 1 in flight, fragments of (K-step 0, sub-step 0) in flight
+#ifdef LAFF_BAND_FIRST
+        if constexpr (EPI == EPI_SIM) band_prefetch<CF>(bptr, r0, c0, wr, wc, lane, pre);
+#endif
         stage_next(0);
         // The banded epilogue's inputs are requested behind the first stage's DMA, under its latency.  (Measured alternatives, all
         // within noise of this one: right behind the first barrier -- +2.3k cycles on K-step 0; behind the last refill piece of
         // K-step 1 with a counted `vmcnt(3 WM)` at that step's barrier so that they stay in flight for a whole K-step -- the next
         // barrier still waits ~1.7k cycles for them: under the DMA stream these 13 requests take ~4k cycles to return.)
+#ifndef LAFF_BAND_FIRST
         if constexpr (EPI == EPI_SIM) band_prefetch<CF>(bptr, r0, c0, wr, wc, lane, pre);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");

@@ -437,7 +437,10 @@ __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restri
 hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64, int* count,
                                float* S, int lds, unsigned* pairs, unsigned pair_cap, hipStream_t st) {
     (void)Nt; (void)Nv;
-    hipLaunchKernelGGL(rank_resolve_kernel, dim3(2048), dim3(256), 0, st, Et, Ev, H, d, s_gt64, count, S, (long)lds, pairs, pair_cap);
+    // one resident round: 16 KiB of LDS and ~70 VGPRs per block admit 7 blocks per CU; 6 x CUs leaves a margin (a second, sparse
+    // round of the 2,048-block grid doubled this launch's time)
+    hipLaunchKernelGGL(rank_resolve_kernel, dim3((unsigned)(6 * g_num_cus)), dim3(256), 0, st, Et, Ev, H, d, s_gt64, count, S, (long)lds, pairs,
+                       pair_cap);
     return hipGetLastError();
 }
 

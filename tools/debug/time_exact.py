@@ -51,3 +51,7 @@ st2.gt_col = torch.full_like(gt, -100000)
 print('band=0, no gt     S %.4f  noS %.4f' % (timeit(lambda: ops.sim_gemm_banded(st2, out=S)), timeit(lambda: ops.sim_gemm_banded(st2, want_scores=False))))
 gtn = torch.full_like(gt, -100000)
 print('legacy, no gt     S %.4f  noS %.4f' % (timeit(lambda: ops.sim_gemm(T, V, heads=heads, out=S, gt_col=gtn, s_gt=sg, count=cnt)), timeit(lambda: ops.sim_gemm(T, V, heads=heads, want_scores=False, gt_col=gtn, s_gt=sg, count=cnt))))
+st3 = ops.rank_prepare(te, ve, T, V, gt)
+st3.band_t.zero_(); st3.band_v.zero_()
+ops.sim_gemm_banded(st3, want_scores=False)
+print('resolve, empty list (scan only) %.4f ms' % timeit(lambda: ops.rank_resolve(st3, None)), st3.listed_pairs(), 'header', st3.pairs[:4].tolist())
