@@ -240,12 +240,13 @@ int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv,
  *   laff_rank_prepare      Et [Nt, H, d], Ev [Nv, H, d]: the fp32 embeddings (rows 16-byte aligned, d % 4 == 0); T, V: the GEMM
  *                          operands made from them (laff_pack_rows / laff_fuse_packed; `precision`, `prescale` as given there).
  *                          Writes s_gt64[t] = exact(t, gt_col[t] - col0) (-inf when that column is outside [0, Nv): another
- *                          shard owns it -- all-reduce MAX the doubles), band_t [Nt] and band_v [Nv + ceil(Nv / 64)] with
+ *                          shard owns it -- all-reduce MAX the doubles), band_t [Nt] and band_v with
  *                          |S_gemm(t, v) - exact(t, v)| <= band_t[t] + band_v[v]  (measured operand rounding error of both rows by
- *                          Cauchy-Schwarz + the fp32 accumulation bound; behind the Nv per-column values: the maximum of every
- *                          aligned block of 64 columns, which is what the GEMM epilogue uses), clears zero_count [Nt] (nullable)
- *                          and the pair-list header.
- *   laff_sim_gemm_banded   laff_sim_gemm whose fused count is exact-decidable: count[t] += #{v != gt : S > s_gt + band}, pairs with
+ *                          Cauchy-Schwarz + the fp32 accumulation bound; behind the per-column values, from offset (Nv + 3) & ~3:
+ *                          the maximum of every aligned block of 64 columns, which is what the GEMM epilogue uses -- band_v holds
+ *                          ((Nv + 3) & ~3) + ceil(Nv / 64) floats), clears zero_count [Nt] (nullable) and the pair-list header.
+ *   laff_sim_gemm_banded   (gt_col, s_gt64, band_t, band_v: 16-byte aligned and readable up to the next multiple of 16 bytes -- the
+ *                          kernel fetches them in 16-byte groups by LDS-DMA.)  laff_sim_gemm whose fused count is exact-decidable: count[t] += #{v != gt : S > s_gt + band}, pairs with
  *                          |S - s_gt| <= band are listed in `pairs` (uint32: header {n_extra, overflow, A, w} then pair_cap x
  *                          {row, col}, col shard-local: A slots in per-wavefront segments of w slots -- valid pairs first, unused
  *                          slots have row 0xffffffff -- then n_extra pairs appended by wavefronts whose segment was too small);

@@ -539,6 +539,8 @@ static int sim_gemm_impl(laff_ctx* ctx, const char* who, const void* T, const vo
     if (s_gt64 && (!gt_col || !band_t || !band_v || !pairs || pair_cap < 1))
         return fail(LAFF_E_ARG, "%s: the banded count needs gt_col, band_t, band_v and a pair list", who);
     if (!aligned16(T) || !aligned16(V)) return fail(LAFF_E_ALIGN, "%s: operands must be 16-byte aligned", who);
+    if (s_gt64 && (!aligned16(gt_col) || !aligned16(s_gt64) || !aligned16(band_t) || !aligned16(band_v)))
+        return fail(LAFF_E_ALIGN, "%s: gt_col, s_gt64, band_t and band_v must be 16-byte aligned (fetched in 16-byte groups)", who);
     laff::GemmArgs a{};
     a.R = T; a.C = V; a.nR = Nt; a.nC = Nv; a.K = K; a.ldR = K; a.ldC = K;
     const long planeT = (long)Nt * K * 2, planeV = (long)Nv * K * 2;

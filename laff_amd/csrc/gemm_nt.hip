@@ -48,7 +48,12 @@ constexpr int ROWB = 128;   // bytes of K per row per K-step
 // pair with its own atomic on the one global counter serialised the whole launch: 92k pairs at C4 x ~12 ns = 1.1 ms for a 0.6 ms
 // kernel; a returning atomic per tile still cost its round trip at the very end of every tile.)
 constexpr int PAIR_LCAP = 1024;
-constexpr int PAIR_LDS = 16 + PAIR_LCAP * 8;
+// ... followed by the per-row inputs of the banded epilogue for the tile's (at most 256) rows, brought in by LDS-DMA next to the first
+// operand stage: gt_col [256] int32 | band_r [256] fp32 | s_gt64 [256] fp64
+constexpr int ROWDATA_OFF = 16 + PAIR_LCAP * 8;
+constexpr int ROWDATA_GT = 0, ROWDATA_BR = 1024, ROWDATA_SG = 2048, ROWDATA_BC = 4096, ROWDATA_BYTES = 5120;
+// (ROWDATA_BC: the 16 bytes of per-64-column band maxima that cover the tile's columns, replicated by every lane of one piece)
+constexpr int PAIR_LDS = ROWDATA_OFF + ROWDATA_BYTES;
 // slots per tile segment: half of the list is split evenly between the tiles, the other half takes the overflow
 __host__ __device__ __forceinline__ unsigned pair_chunk(unsigned pair_cap, unsigned ntiles) {
     unsigned c = (pair_cap / 2u) / (ntiles ? ntiles : 1u);
@@ -290,8 +295,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
 // count[row] += #{col != gt : S > s_gt + band}; the pairs with |S - s_gt| <= band are staged for laff_rank_resolve (rank.hip), which
 // re-scores them exactly; S (optional) gets the exact ground-truth score at the ground-truth entry.  band = band_r[row] + the
 // maximum of band_c over the wave's 64 columns (computed once per 64-column block by laff_rank_prepare: one value per wave).
-//   * Everything this epilogue reads from global memory (gt_col, s_gt64, band_r of the lane's WM rows; the wave's column-block band)
-//     is fetched BEFORE the K loop (BandPre): an L2 round trip per 32-row block in front of the stores was ~1/4 of this epilogue.
+//   * The per-row inputs (gt_col, s_gt64, band_r of the tile's rows) arrive in LDS by DMA next to the first operand stage
+//     (band_stage_rows): an L2 round trip per 32-row block in front of the stores was ~1/4 of this epilogue.
 //   * The tests run in ACCUMULATOR units -- thresholds lo = (s_gt - band) / scale, hi = (s_gt + band) / scale per row -- and with
 //     vector registers only: two per-lane counters (x > hi, x >= lo), i.e. two compares and two add-with-carry per element and no
 //     VALU -> SGPR -> SALU hazard stalls; a 32x32 block holds a pair in the band iff the two counters moved apart: ONE lane-mask
@@ -300,65 +305,60 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
 //     wave-private LDS list: no LDS atomics, no workgroup barrier.
 //   * Each WAVE publishes its list into its own fixed segment of the global list (unused slots marked invalid): no global atomic.
 //     Only a wave with more pairs than its segment appends the excess behind the segments with the global counter.
+// Row inputs of the banded epilogue -> LDS, by LDS-DMA: waves 0..4 issue ONE extra 1 KiB piece each (gt_col, band_r, two halves of
+// s_gt64 for a 256-row tile, the column-block band maxima) right behind their pieces of the first operand stage.  Being the youngest requests of those waves they
+// are left in flight by the prologue's wait (`vmcnt(1)`) and are covered by the `vmcnt(0)` + barrier of the first K-step: no
+// registers, no address arithmetic, no wait of their own.  (As per-lane register loads the same 13 requests -- cold lines written
+// by laff_rank_prepare on other XCDs -- cost 1.7k cycles per tile wherever they were issued: in front of the first barrier, behind
+// it, or in the middle of the K loop with a counted wait.)  A lane fetches the aligned 16 bytes that hold its rows; groups beyond
+// the last row are redirected to the last valid group (their rows are never used), so the arrays must be 16-byte aligned and
+// readable up to the next multiple of 16 bytes (any hipMalloc / torch allocation is).
 template <typename CF>
-struct BandPre {
-    int gt[CF::WM];           // ground-truth column of the lane's row in each 32-row block, relative to this shard (or < 0)
-    double sg[CF::WM];        // exact ground-truth score
-    float br[CF::WM];         // row part of the band
-    float bc;                 // column part of the band: maximum over the wave's WN*32 columns
-};
-
-// The kernel arguments the prefetch needs, read ONCE at the top of the tile and pinned in scalar registers: left to the compiler they
-// are re-fetched (s_load + lgkmcnt(0) wait, which also drains the hand-counted LDS reads) right where the prefetch sits in the K
-// loop: ~1.3k cycles per tile.  They are pinned as integers and turned back into GLOBAL pointers at the use: laundering the
-// pointers themselves strips their address space and the loads become FLAT loads, which count in lgkmcnt as well.
-typedef const int __attribute__((address_space(1)))* gptr_i32;
-typedef const double __attribute__((address_space(1)))* gptr_f64;
-typedef const float __attribute__((address_space(1)))* gptr_f32;
-struct BandPtrs {
-    unsigned long long gt_col, s_gt64, band_r, band_c;
-    int col0, nR, nC, on;
-};
-__device__ __forceinline__ BandPtrs band_ptrs(const GemmArgs& a) {
-    BandPtrs q{uniform64((unsigned long long)a.gt_col), uniform64((unsigned long long)a.s_gt64), uniform64((unsigned long long)a.band_r),
-               uniform64((unsigned long long)a.band_c), __builtin_amdgcn_readfirstlane(a.col0), __builtin_amdgcn_readfirstlane(a.nR),
-               __builtin_amdgcn_readfirstlane(a.nC),
-               __builtin_amdgcn_readfirstlane((a.s_gt64 != nullptr && a.count != nullptr) ? 1 : 0)};
-    asm volatile("" : "+s"(q.gt_col), "+s"(q.s_gt64), "+s"(q.band_r), "+s"(q.band_c), "+s"(q.col0), "+s"(q.nR), "+s"(q.nC), "+s"(q.on));
-    return q;
-}
-
-template <typename CF>
-__device__ __forceinline__ void band_prefetch(const BandPtrs& a, int r0, int c0, int wr, int wc, int lane, BandPre<CF>& p) {
-    constexpr int WM = CF::WM, WN = CF::WN;
-    const bool on = a.on != 0;
-    p.bc = 0.0f;
-    gptr_f32 blk = (gptr_f32)a.band_c + a.nC;                   // [ceil(nC / 64)] maxima of band_c over aligned 64-column blocks
-#pragma unroll
-    for (int i = 0; i < WN / 2; ++i) {
-        const int c = c0 + wc * (WN * 32) + i * 64;             // wave-uniform
-        if (on && c < a.nC) p.bc = fmaxf(p.bc, blk[c >> 6]);
+__device__ __forceinline__ int band_stage_rows(const GemmArgs& a, int r0, int c0, int wave, int lane, unsigned lds0) {
+    constexpr int TR = CF::TR;
+    const bool on = a.s_gt64 != nullptr && a.count != nullptr;
+    const unsigned dst = lds0 + (unsigned)CF::SMEM + (unsigned)ROWDATA_OFF;
+    // piece w of waves 0..3: 0 = gt_col (4 rows per lane), 1 = band_r (4 rows per lane), 2/3 = s_gt64 rows [0,128) / [128,256) (2 per lane)
+    constexpr int NP = TR > 128 ? 4 : 3;
+    if (!on || wave > NP) return 0;
+    const int last = a.nR - 1;
+    if (wave == NP) {
+        // column-block band maxima: laff_rank_prepare stores them behind the per-column values at the 16-byte aligned offset
+        // (nC + 3) & ~3; every lane fetches the aligned group of 4 that holds the tile's first block
+        const int nblk = (a.nC + 63) >> 6;
+        const int g = min((c0 >> 6) & ~3, (nblk - 1) & ~3);
+        const unsigned long long base = uniform64((unsigned long long)(const void*)(a.band_c + ((a.nC + 3) & ~3)));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"((unsigned)g * 4u), "s"(base), "s"(__builtin_amdgcn_readfirstlane(dst + ROWDATA_BC))
+                     : "memory");
+        return 1;
     }
-#pragma unroll
-    for (int tr = 0; tr < WM; ++tr) {
-        const int rr = r0 + wr * (WM * 32) + tr * 32 + (lane & 31);
-        const bool ok = on && rr < a.nR;
-        p.gt[tr] = ok ? ((gptr_i32)a.gt_col)[rr] - a.col0 : -1;
-        p.sg[tr] = ok ? ((gptr_f64)a.s_gt64)[rr] : 0.0;
-        p.br[tr] = ok ? ((gptr_f32)a.band_r)[rr] : 0.0f;
+    if (wave < 2) {
+        const int g = min(r0 + 4 * lane, last & ~3);                      // first row of this lane's group of 4
+        const unsigned long long base = uniform64((unsigned long long)(wave == 0 ? (const void*)a.gt_col : (const void*)a.band_r));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"((unsigned)g * 4u), "s"(base), "s"(__builtin_amdgcn_readfirstlane(dst + (wave == 0 ? ROWDATA_GT : ROWDATA_BR)))
+                     : "memory");
+    } else {
+        const int half = wave - 2;
+        const int g = min(r0 + 128 * half + 2 * lane, last & ~1);         // first row of this lane's pair
+        const unsigned long long base = uniform64((unsigned long long)(const void*)a.s_gt64);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"((unsigned)g * 8u), "s"(base), "s"(__builtin_amdgcn_readfirstlane(dst + ROWDATA_SG + 1024 * half))
+                     : "memory");
     }
-}
-// keeps the prefetched values (and therefore their loads) in front of the K loop: a use the compiler cannot move
-template <typename CF>
-__device__ __forceinline__ void band_pin(BandPre<CF>& p) {
-    asm volatile("" : "+v"(p.bc));
-#pragma unroll
-    for (int tr = 0; tr < CF::WM; ++tr) asm volatile("" : "+v"(p.gt[tr]), "+v"(p.sg[tr]), "+v"(p.br[tr]));
+    return 1;
 }
 
 template <bool FULL, typename CF>
 __device__ __forceinline__ void epilogue_banded(const GemmArgs& a, f32x16 (&acc)[CF::WM][CF::WN], int r0, int c0, int wr, int wc,
-                                                int wave, int lane, char* smem, const BandPre<CF>& pre) {
+                                                int wave, int lane, char* smem) {
     constexpr int WM = CF::WM, WN = CF::WN, PITCH = CF::PITCH, NWAVES = CF::THREADS / 64;
     constexpr unsigned WCAP = PAIR_LCAP / NWAVES;                           // staged pairs per wave
     const int l31 = lane & 31, hh = lane >> 5;
@@ -375,14 +375,36 @@ __device__ __forceinline__ void epilogue_banded(const GemmArgs& a, f32x16 (&acc)
 #endif
     ETRACE(0);
     const float inv_scale = 1.0f / a.scale;
+    // the wave's column-block band (one wave-uniform value) and the lane's rows from the LDS copy the prologue brought in
+    const char* rowdata = smem + CF::SMEM + ROWDATA_OFF;
+    float bc = 0.0f;
+    {
+        const int nblk = (a.nC + 63) >> 6;
+        const int g0 = min((c0 >> 6) & ~3, (nblk - 1) & ~3);     // first block of the staged group of 4 (see band_stage_rows)
+#pragma unroll
+        for (int i = 0; i < WN / 2; ++i) {
+            const int c = cw0 + i * 64;                         // wave-uniform
+            if (c < a.nC) bc = fmaxf(bc, ((const float*)(rowdata + ROWDATA_BC))[(c >> 6) - g0]);
+        }
+    }
+    int gt_[WM];
+    float br_[WM];
+    double sg_[WM];
+#pragma unroll
+    for (int tr = 0; tr < WM; ++tr) {
+        const int rt = wr * (WM * 32) + tr * 32 + l31;          // row inside the tile
+        gt_[tr] = ((const int*)(rowdata + ROWDATA_GT))[rt] - a.col0;
+        br_[tr] = ((const float*)(rowdata + ROWDATA_BR))[rt];
+        sg_[tr] = ((const double*)(rowdata + ROWDATA_SG))[rt];
+    }
 #pragma unroll
     for (int tr = 0; tr < WM; ++tr) {
         const int rbase = r0 + wr * (WM * 32) + tr * 32;
         const int rr = rbase + l31;
         const bool row_ok = FULL || rr < a.nR;
         ETRACE(1 + tr);
-        const int gt = pre.gt[tr];
-        const float sg = (float)pre.sg[tr], eps = pre.br[tr] + pre.bc;
+        const int gt = row_ok ? gt_[tr] : -1;
+        const float sg = (float)sg_[tr], eps = br_[tr] + bc;
         // accumulator-unit thresholds (the band's constant term carries the rounding of these two products)
         const float lo = (sg - eps) * inv_scale, hi = (sg + eps) * inv_scale;
         int c_hi = 0, c_lo = 0;                                             // #{x > hi}, #{x >= lo} over this lane's elements
@@ -529,8 +551,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
     constexpr int ESZ = ModeTraits<MODE>::ESZ;
     constexpr int WM = CF::WM, WN = CF::WN, THREADS = CF::THREADS;
     constexpr bool GLDS = STG != 0;
-    BandPtrs bptr{};
-    if constexpr (EPI == EPI_SIM) bptr = band_ptrs(a);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -615,10 +635,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
 #pragma unroll
     for (int ks = 0; ks < ROWB / 32; ++ks) xk[ks] = (unsigned)(((2 * ks + hh) ^ ((l31 >> 1) & 7)) * 16);
 
-    // inputs of the banded count (EPI_SIM): fetched here, used after the K loop
-    BandPre<CF> pre;
     const bool banded = EPI == EPI_SIM && a.s_gt64 != nullptr && a.count != nullptr;
-    if constexpr (EPI == EPI_SIM && STG != 2) band_prefetch<CF>(bptr, r0, c0, wr, wc, lane, pre);
     TRACE(1);
     if constexpr (STG == 2) {
         // ---- software-pipelined K loop (fast staging) ---------------------------------------------------------------
@@ -695,18 +712,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         using IC0 = std::integral_constant<int, 0>;
         static_assert(NSUB % 2 == 0, "fragment buffer parity must repeat every K-step");
         // prologue: stage 0 landed and visible, stage 1 in flight, fragments of (K-step 0, sub-step 0) in flight
-#ifdef LAFF_BAND_FIRST
-        if constexpr (EPI == EPI_SIM) band_prefetch<CF>(bptr, r0, c0, wr, wc, lane, pre);
-#endif
         stage_next(0);
-        // The banded epilogue's inputs are requested behind the first stage's DMA, under its latency.  (Measured alternatives, all
-        // within noise of this one: right behind the first barrier -- +2.3k cycles on K-step 0; behind the last refill piece of
-        // K-step 1 with a counted `vmcnt(3 WM)` at that step's barrier so that they stay in flight for a whole K-step -- the next
-        // barrier still waits ~1.7k cycles for them: under the DMA stream these 13 requests take ~4k cycles to return.)
-#ifndef LAFF_BAND_FIRST
-        if constexpr (EPI == EPI_SIM) band_prefetch<CF>(bptr, r0, c0, wr, wc, lane, pre);
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // row inputs of the banded epilogue: one extra DMA piece for waves 0..3, left in flight by this wait (see band_stage_rows)
+        int extra = 0;
+        if constexpr (EPI == EPI_SIM) extra = band_stage_rows<CF>(a, r0, c0, wave, lane, lds0);
+        if (extra && nkt > 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");       // wave-uniform
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         TRACE(2);
@@ -771,7 +782,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
             mfmas((NSUB - 1) & 1, IC0{}, std::integral_constant<int, NP0>{}, fill_on);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (EPI == EPI_SIM) band_pin<CF>(pre);
 #ifdef LAFF_GEMM_TRACE
         if (a.trace && tid == 0) {
             unsigned long long* t2 = a.trace + (long)gridDim.x * 8 + (long)blockIdx.x * 8;
@@ -781,6 +791,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
 #endif
     } else {
         // ---- generic staging paths: compiler-scheduled loop, one barrier pair per K-step ------------------------------
+        if constexpr (EPI == EPI_SIM) (void)band_stage_rows<CF>(a, r0, c0, wave, lane, lds0);   // landed + visible after the first barrier
         stage_next(0);
         for (int kt = 0; kt < nkt; ++kt) {
             if constexpr (GLDS) {
@@ -830,8 +841,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
     const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
                       ((((uintptr_t)a.out) & 15) == 0);
     if (EPI == EPI_SIM && banded) {
-        if (full) epilogue_banded<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, pre);
-        else epilogue_banded<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, pre);
+        if (full) epilogue_banded<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+        else epilogue_banded<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     } else if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     TRACE(6);
@@ -867,8 +878,6 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     static_assert(MODE == GEMM_F16 || MODE == GEMM_BF16, "the split product runs on the 16-bit matrix pipe");
     using CF = CfgX3;
     constexpr int WM = CF::WM, WN = CF::WN, THREADS = CF::THREADS, RB = CF::ROWB, CPR = CF::CPR;
-    BandPtrs bptr{};
-    if constexpr (EPI == EPI_SIM) bptr = band_ptrs(a);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -1016,19 +1025,20 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     using I4 = std::integral_constant<int, 4>;
     using I6 = std::integral_constant<int, 6>;
 
-    BandPre<CF> pre;
     const bool banded = EPI == EPI_SIM && a.s_gt64 != nullptr && a.count != nullptr;
     // prologue: stage 0 landed and visible, stage 1 in flight, operands of the first B group (C_lo, R_hi of slice 0) in flight
     fill_begin(0, 0);
     if constexpr (RF32) xload();
     fill_all();
-    if constexpr (EPI == EPI_SIM) band_prefetch<CF>(bptr, r0, c0, wr, wc, lane, pre);   // under the first stage's load latency
+    int extra = 0;
+    if constexpr (EPI == EPI_SIM) extra = band_stage_rows<CF>(a, r0, c0, wave, lane, lds0);     // see band_stage_rows
     if constexpr (RF32) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[1][0]), "+v"(xs[1][1])::"memory");
         xconvert();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (extra && nkt > 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");     // wave-uniform
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1098,13 +1108,12 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
         }
     }
 
-    if constexpr (EPI == EPI_SIM) band_pin<CF>(pre);
     __syncthreads();                                   // every wave is done reading the operand ring
     const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
                       ((((uintptr_t)a.out) & 15) == 0);
     if (EPI == EPI_SIM && banded) {
-        if (full) epilogue_banded<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, pre);
-        else epilogue_banded<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem, pre);
+        if (full) epilogue_banded<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+        else epilogue_banded<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     } else if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
 }

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
         if (threadIdx.x == 0) {
             float m = 0.0f;
             for (int i = 0; i < PREP_ROWS; ++i) m = fmaxf(m, blkmax[i]);
-            band_v[Nv + vb] = m;
+            band_v[((Nv + 3) & ~3) + vb] = m;          // block maxima start at a 16-byte aligned offset (the GEMM fetches them by DMA)
         }
     }
 }

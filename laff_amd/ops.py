@@ -543,11 +543,13 @@ def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None):
     _dev(gt_col, 'gt_col', torch.int32)
     if gt_col.numel() != Nt or not gt_col.is_contiguous():
         raise ValueError('gt_col must be a contiguous int32 vector of %d' % Nt)
+    if gt_col.data_ptr() % 16:          # the GEMM fetches gt_col in 16-byte groups
+        gt_col = gt_col.clone()
     dev = Et.device
     cap = int(pair_cap) if pair_cap is not None else default_pair_cap(Nt)
-    s_gt64 = torch.empty((Nt,), device=dev, dtype=torch.float64)
-    band_t = torch.empty((max(Nt, 1),), device=dev, dtype=torch.float32)
-    band_v = torch.empty((Nv + (Nv + 63) // 64 + 4,), device=dev, dtype=torch.float32)     # per column, then per 64-column block
+    s_gt64 = torch.empty((Nt + 2,), device=dev, dtype=torch.float64)[:Nt]
+    band_t = torch.empty((Nt + 4,), device=dev, dtype=torch.float32)          # (+ slack: the GEMM fetches 16-byte groups)
+    band_v = torch.empty((((Nv + 3) & ~3) + (Nv + 63) // 64 + 4,), device=dev, dtype=torch.float32)     # per column, then (16-byte aligned) per 64-column block
     count = torch.empty((Nt,), device=dev, dtype=torch.int32)
     pairs = torch.empty((4 + 2 * cap,), device=dev, dtype=torch.int32)
     lib, h = _context(dev)
