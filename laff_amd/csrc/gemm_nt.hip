@@ -94,6 +94,18 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 }
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// Lanes of one wavefront exchanging data through LDS: the hardware executes a wavefront's LDS operations in order, so all that is
+// needed is that the COMPILER keeps the stores in front of the loads (and the loads in front of the next stores).
+// __builtin_amdgcn_wave_barrier() alone is declared without memory effects, so per-thread alias analysis (a lane's own store and
+// load addresses differ) would be free to move one across the other; the fences make the ordering explicit.
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
+}
+
 // ---- staging, generic paths (STG 0: through registers, element-wise K bounds; STG 1: LDS-DMA with per-step address
 // arithmetic, 16-byte K granularity).  One operand tile = ROWS x 8 chunks of 16 B; LDS slot p = row*8 + cs holds
 // source chunk swz(row, cs).
@@ -261,7 +273,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
             if (hh == 0 && row_ok && cnt) atomicAdd(a.count + rr, cnt);
         }
         if (a.out) {
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_fence();
             constexpr int LPR = WN * 8, RPI = 64 / LPR;      // lanes per slab row, rows per store instruction
             const int col4 = (lane % LPR) * 4;
             const int gc = cw0 + col4;
@@ -286,7 +298,118 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[CF::WM
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();            // slab is rewritten by the next 32-row block
+            wave_lds_fence();                           // slab is rewritten by the next 32-row block
+        }
+    }
+}
+
+// ---- FC epilogue: row/column scales of the operand split, bias, activation, folded BatchNorm ---------------------------------
+// The per-column parameters (col_scale, bias, bn_scale, bn_shift: 4 x 16 bytes per quad of columns) depend on the column only.  The
+// generic epilogue above fetched them inside the (row block, column block, quad) loop, behind the previous block's stores (the
+// compiler cannot hoist a load across a store through an unrelated pointer): 32 dependent L2 round trips per lane -- the epilogue
+// took 25-31k cycles of a 112k-cycle fused-split tile (tools/debug/trace_fc.py), three times the similarity GEMM's.  Here the
+// column block is the OUTER loop: its 16 parameter vectors are loaded once into registers (64 VGPRs: the K loop's fragment registers
+// are dead by now) and reused for all WM row blocks; each (row block, column block) goes through a 32 x 32 slab, every store
+// instruction writes 8 rows x 128 contiguous bytes (whole cache lines: tile columns are multiples of 32).
+template <bool FULL, typename CF>
+__device__ __forceinline__ void epilogue_fc(const GemmArgs& a, f32x16 (&acc)[CF::WM][CF::WN], int r0, int c0, int wr, int wc,
+                                            int wave, int lane, char* smem) {
+    constexpr int WM = CF::WM, WN = CF::WN, P32 = 36;                       // slab pitch in words: 32 columns + 4
+    const int l31 = lane & 31, hh = lane >> 5;
+    float* slab = (float*)smem + wave * (32 * P32);
+    const int cw0 = c0 + wc * (WN * 32);
+    float rscl[WM];
+#pragma unroll
+    for (int tr = 0; tr < WM; ++tr) {
+        const int rr = r0 + wr * (WM * 32) + tr * 32 + l31;
+        rscl[tr] = a.scale;
+        if (a.row_scale && (FULL || rr < a.nR)) rscl[tr] *= a.row_scale[rr];
+    }
+#pragma unroll
+    for (int tc = 0; tc < WN; ++tc) {
+        float cs[4][4], bb[4][4], ss[4][4], hs[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cc = cw0 + tc * 32 + 8 * q + 4 * hh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[q][e] = 1.0f; bb[q][e] = 0.0f; ss[q][e] = 1.0f; hs[q][e] = 0.0f; }
+            if (FULL || cc + 3 < a.nC) {
+                auto ld4 = [](const float* p, float (&o)[4]) {
+                    const float4 t = *(const float4*)p;
+                    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+                };
+                if (a.col_scale) ld4(a.col_scale + cc, cs[q]);
+                if (a.bias) ld4(a.bias + cc, bb[q]);
+                if (a.bn_scale) {
+                    ld4(a.bn_scale + cc, ss[q]);
+                    ld4(a.bn_shift + cc, hs[q]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (cc + e < a.nC) {
+                        if (a.col_scale) cs[q][e] = a.col_scale[cc + e];
+                        if (a.bias) bb[q][e] = a.bias[cc + e];
+                        if (a.bn_scale) { ss[q][e] = a.bn_scale[cc + e]; hs[q][e] = a.bn_shift[cc + e]; }
+                    }
+            }
+        }
+#pragma unroll
+        for (int tr = 0; tr < WM; ++tr) {
+            const int rbase = r0 + wr * (WM * 32) + tr * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[tr][tc][4 * q + e] * rscl[tr];
+                // The four products are pinned in registers before the multiply-adds.  Written as one expression, the compiler emits
+                //   v_pk_mul_f32 P, acc, rscl ; s_nop 0 ; v_pk_fma_f32 .., P, .. ; v_pk_mul_f32 P, .. ; s_nop 0 ; v_pk_fma_f32 .., P, ..
+                // directly behind the previous block's four 16-byte stores, and on MI355X that sequence sporadically delivered a STALE
+                // P to the second multiply-add in lanes 48..63 (measured: ~20 events of 16 rows x 1 column per 416-tile launch, only in
+                // workgroups that are not the first on their CU, only in the first quad of row blocks 1 and 3; any change of the
+                // sequence -- this pin, plain v_mul_f32, even moving the slab 64 KiB up in LDS -- gave 0 events in 30 x 416 tiles,
+                // tools/debug/stress_fc.py).  Cause not established; the pin costs two VALU issue slots per quad.
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], cs[q][e], bb[q][e]);
+                if (a.act == 1) {                          // wave-uniform
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fast_tanh(v[e]);
+                } else if (a.act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                } else if (a.act == 3) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fast_sigmoid(v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], ss[q][e], hs[q][e]);
+                *(float4*)(slab + l31 * P32 + 8 * q + 4 * hh) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            wave_lds_fence();
+            const int col4 = (lane & 7) * 4;
+            const int gc = cw0 + tc * 32 + col4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = (lane >> 3) + 8 * j;
+                const float4 v = *(const float4*)(slab + row * P32 + col4);
+                const int gr = rbase + row;
+                float* o = a.out + (long)gr * a.ldo + gc;
+                if constexpr (FULL) {
+                    __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), (f32x4*)o);     // keeps the operand panels in L2
+                } else if (gr < a.nR) {
+                    const bool vec_ok = ((a.ldo & 3) == 0) && ((((uintptr_t)a.out) & 15) == 0);
+                    if (vec_ok && gc + 3 < a.nC) {
+                        *(float4*)o = v;
+                    } else {
+                        const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (gc + e < a.nC) o[e] = t[e];
+                    }
+                }
+            }
+            wave_lds_fence();                           // the slab is rewritten by the next block
         }
     }
 }
@@ -479,7 +602,7 @@ __device__ __forceinline__ void epilogue_banded(const GemmArgs& a, f32x16 (&acc)
         int cnt = c_hi + __shfl_xor(c_hi, 32);
         if (hh == 0 && row_ok && cnt) atomicAdd(a.count + rr, cnt);
         if (a.out) {
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_fence();
             constexpr int LPR = WN * 8, RPI = 64 / LPR;      // lanes per slab row, rows per store instruction
             const int col4 = (lane % LPR) * 4;
             const int gc = cw0 + col4;
@@ -503,7 +626,7 @@ __device__ __forceinline__ void epilogue_banded(const GemmArgs& a, f32x16 (&acc)
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();            // slab is rewritten by the next 32-row block
+            wave_lds_fence();                           // slab is rewritten by the next 32-row block
         }
     }
     ETRACE(5);
@@ -843,6 +966,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
     if (EPI == EPI_SIM && banded) {
         if (full) epilogue_banded<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
         else epilogue_banded<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    } else if constexpr (EPI == EPI_FC) {
+        if (full) epilogue_fc<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+        else epilogue_fc<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     } else if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     TRACE(6);
@@ -886,6 +1012,15 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
 
     const long ldRb = (long)a.ldR * 2, ldCb = (long)a.ldC * 2;
     const int nkt = (int)(((long)a.K * 2) / RB);                  // K bytes are a multiple of 64 on this path (128 unless RF32)
+#ifdef LAFF_GEMM_TRACE
+#define XTRACE(i) do { if (a.trace && tid == 0) a.trace[(long)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+    if (a.trace && tid == 0)
+        a.trace[(long)blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xf814) /*XCC_ID*/ << 32) |
+                                           __builtin_amdgcn_s_getreg(0xf804) /*HW_ID*/;
+#else
+#define XTRACE(i) do {} while (0)
+#endif
+    XTRACE(0);
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -1026,6 +1161,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     using I6 = std::integral_constant<int, 6>;
 
     const bool banded = EPI == EPI_SIM && a.s_gt64 != nullptr && a.count != nullptr;
+    XTRACE(1);
     // prologue: stage 0 landed and visible, stage 1 in flight, operands of the first B group (C_lo, R_hi of slice 0) in flight
     fill_begin(0, 0);
     if constexpr (RF32) xload();
@@ -1049,8 +1185,9 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     }
     rd_fc(1, 0, 0, 1);
     rd_fr(1, 0, 0, 0);
-
+    XTRACE(2);
     for (int kt = 0; kt < nkt; ++kt) {
+        if (kt == 1) XTRACE(3);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             // ---- B: R_hi . C_lo (set 1); meanwhile fetch C_hi -> fc[0], R_lo -> fr[0] of this slice
@@ -1108,14 +1245,21 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
         }
     }
 
+    XTRACE(4);
     __syncthreads();                                   // every wave is done reading the operand ring
+    XTRACE(5);
     const bool full = (r0 + CF::TR <= a.nR) && (c0 + CF::TC <= a.nC) && ((a.ldo & 3) == 0) &&
                       ((((uintptr_t)a.out) & 15) == 0);
     if (EPI == EPI_SIM && banded) {
         if (full) epilogue_banded<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
         else epilogue_banded<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    } else if constexpr (EPI == EPI_FC) {
+        if (full) epilogue_fc<true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+        else epilogue_fc<false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     } else if (full) epilogue<EPI, true, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
     else epilogue<EPI, false, CF>(a, acc, r0, c0, wr, wc, wave, lane, smem);
+    XTRACE(6);
+#undef XTRACE
 }
 
 template <int MODE>

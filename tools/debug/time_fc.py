@@ -21,13 +21,15 @@ Xs=ops.split_rows_grouped(X)
 b=torch.randn(D,device=dev)*0.1; sc=torch.rand(D,device=dev)+0.5; sh=torch.randn(D,device=dev)*0.1
 outs=[torch.empty(n,D,device=dev) for n in rows]
 flop=sum(2.0*n*512*D*3 for n in rows)
-def run(act, bn, sub=None):
+def run(act, bn, sub=None, fused=False):
     idx=range(len(rows)) if sub is None else sub
-    probs=[dict(x=Xs[i], weight_split=Ws[i], bias=b, bn_scale=sc if bn else None, bn_shift=sh if bn else None, activation=act, out=outs[i]) for i in idx]
+    probs=[dict(x=X[i] if fused else Xs[i], weight_split=Ws[i], bias=b, bn_scale=sc if bn else None, bn_shift=sh if bn else None, activation=act, out=outs[i]) for i in idx]
     return lambda: ops.fc_act_bn_split_grouped(probs)
 for name,fn,fl in [('8 problems tanh+bn',run('tanh',True),flop),('8 problems no act/bn',run(None,False),flop),
                 ('4 x 40000 rows tanh+bn',run('tanh',True,range(4)),flop*0.8),('1 x 40000 rows',run('tanh',True,[0]),flop*0.2),
-                ('4 x 10000 rows',run('tanh',True,range(4,8)),flop*0.2)]:
+                ('4 x 10000 rows',run('tanh',True,range(4,8)),flop*0.2),
+                ('FUSED 8 problems tanh+bn',run('tanh',True,None,True),flop),('FUSED 8 problems no act/bn',run(None,False,None,True),flop),
+                ('FUSED 4 x 40000 tanh+bn',run('tanh',True,range(4),True),flop*0.8)]:
     ms=timeit(fn); print('%-26s %.4f ms  %.0f TF (x3 flops)'%(name,ms,fl/ms/1e9))
 # the same contraction as ONE similarity-style GEMM: 200000 x 512 x (K=512 x3)
 t=torch.nn.functional.normalize(torch.randn(200000,512,device=dev),dim=1); v=torch.nn.functional.normalize(torch.randn(512,512,device=dev),dim=1)
