@@ -39,3 +39,12 @@ for k in np.unique(key):
     m = key == k; st = np.sort(a[m, 0]); en = a[m, 6][np.argsort(a[m, 0])]
     gaps.extend((st[1:] - en[:-1]).tolist())
 print('tiles', nb, 'distinct CUs', len(np.unique(key)), 'gap between tiles on a CU: mean %.0f p50 %.0f' % (np.mean(gaps), np.median(gaps)))
+span = a[:, 6].max() - a[:, 0].min()
+cnt = np.array([np.sum(key == k) for k in np.unique(key)])
+print('launch span %d cycles; tiles per CU: min %d max %d; busy fraction of the span (sum of WG totals / CUs / span): %.3f' % (
+    span, cnt.min(), cnt.max(), tot.sum() / len(cnt) / span))
+# when does each CU finish its last tile, relative to the span
+last = np.array([a[key == k, 6].max() for k in np.unique(key)]) - a[:, 0].min()
+print('CU finish time / span: p10 %.2f p50 %.2f p90 %.2f' % tuple(np.percentile(last / span, [10, 50, 90])))
+first = np.array([a[key == k, 0].min() for k in np.unique(key)]) - a[:, 0].min()
+print('CU first start (cycles): p50 %.0f p90 %.0f max %.0f' % (np.median(first), np.percentile(first, 90), first.max()))
