@@ -26,3 +26,13 @@ for k in (1, 4, 8, 12, 16, 24):
     csr = torch.sparse_csr_tensor(crow, col, torch.ones(N * k, device=dev), size=(N, Dk))
     t0 = timeit(lambda: ops.fuse([(None, False, sc, sh, 'tanh', (csr, wt, bias)), (clip, True, sc, sh)], H, d, w, b, gw, flags, packed_precision='fp16'))
     print('rows per caption %2d: %.4f ms' % (k, t0))
+# the alternative: a separate gather-FC launch writing the projected plane, then a fuse over two ordinary planes
+k = 14
+crow = (torch.arange(N + 1, device=dev) * k).int()
+col = torch.clamp((Dk ** torch.rand(N * k, device=dev) - 1.0).long(), 0, Dk - 1).int()
+csr = torch.sparse_csr_tensor(crow, col, torch.ones(N * k, device=dev), size=(N, Dk))
+t_g = timeit(lambda: ops.fc_gather_act_bn(csr, wt, bias, sc, sh, 'tanh'))
+y = ops.fc_gather_act_bn(csr, wt, bias, sc, sh, 'tanh')
+t_f = timeit(lambda: ops.fuse([(y, False, None, None), (clip, True, sc, sh)], H, d, w, b, gw, flags, packed_precision='fp16'))
+t_i = timeit(lambda: ops.fuse([(None, False, sc, sh, 'tanh', (csr, wt, bias)), (clip, True, sc, sh)], H, d, w, b, gw, flags, packed_precision='fp16'))
+print('14 rows per caption: separate gather FC %.4f ms + fuse of two dense planes %.4f ms = %.4f ms;  gather inside the fuse launch %.4f ms' % (t_g, t_f, t_g + t_f, t_i))
