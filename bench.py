@@ -514,7 +514,8 @@ def main():
                                             + ('; algorithmic %.0f MB' % (alg / 1e6) if alg else ''))
                     break
             else:
-                roof['traffic_note'] = 'no PMC measurement under profiles/ matches the current kernel sources (src_sha %s)' % sha
+                roof['traffic_note'] = ('no PMC measurement under profiles/ matches this run: needs kernel sources src_sha %s, workload %s, '
+                                        'precision %s / %s, one GPU' % (sha, args.workload, args.precision, args.fc_precision))
         except Exception as e:  # noqa: BLE001
             roof['traffic_note'] = 'traffic lookup failed: %s' % e
         m = res['metrics']
