@@ -1374,6 +1374,7 @@ static hipError_t launch_m(const GemmArgs& a, bool aligned, hipStream_t st) {
         const long tiles256 = (long)((a.nR + 255) / 256) * ((a.nC + 255) / 256);
         const bool big = g_gemm_variant == 256 || g_gemm_variant == 3 || (g_gemm_variant != 128 && tiles256 >= 512);
         if (big && a.nseg == 3 && g_gemm_variant != 256) return launch_x3<MODE>(a, st);
+        if (g_gemm_variant == 512) return launch_t<MODE, 2, Cfg<4, 4, 2, 2>>(a, st);      // 4 waves of 128x128 (one 512-register wave per SIMD)
         if (big) return launch_t<MODE, 2, Cfg256>(a, st);
     }
     return launch_t<MODE, 2, Cfg128>(a, st);

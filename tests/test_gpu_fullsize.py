@@ -309,6 +309,33 @@ def test_split_fc_with_tail_split_matches_fp32_path():
         assert float((outs[i] - ref).abs().max()) <= 2e-5
 
 
+@pytest.mark.parametrize('act', ['tanh', 'relu', None])
+def test_grouped_fc_every_element_over_repeated_launches(act):
+    """Every output element of the grouped fused-split FC at the C2 shapes (416 tiles: most CUs run a second workgroup), over repeated
+    launches, against the single-problem fp32 FC.  Guards the sporadic stale-operand events described at `epilogue_fc` (gemm_nt.hip):
+    ~20 blocks of 16 rows x 1 column per launch before the fix (tools/debug/stress_fc.py is the long version)."""
+    from laff_amd import ops
+    torch.manual_seed(5)
+    rows = [3000] * 4 + [10000] * 4
+    W = [torch.randn(512, 512, device=DEV) / 22 for _ in rows]
+    Ws = [ops.split_rows(w) for w in W]
+    X = [torch.randn(n, 512, device=DEV) for n in rows]
+    b = torch.randn(512, device=DEV) * 0.1
+    sc = torch.rand(512, device=DEV) + 0.5
+    sh = torch.randn(512, device=DEV) * 0.1
+    probs = [dict(x=X[i], weight_split=Ws[i], bias=b, bn_scale=sc, bn_shift=sh, activation=act) for i in range(8)]
+    refs = [ops.fc_act_bn(X[i], W[i], b, sc, sh, act) for i in range(8)]
+    first = None
+    for rep in range(12):
+        outs = ops.fc_act_bn_split_grouped(probs)
+        for o, r in zip(outs, refs):
+            assert float((o - r).abs().max()) <= 3e-5
+        if first is None:
+            first = [o.clone() for o in outs]
+        else:
+            assert all(torch.equal(o, f) for o, f in zip(outs, first))          # launches are reproducible bit for bit
+
+
 def test_fused_input_split_is_bit_identical_to_the_materialised_split():
     """laff_fc_act_bn_fused_grouped (inputs split inside the GEMM) against laff_split_rows + laff_fc_act_bn_split_grouped on the
     same big tiles: the planes are formed by the same arithmetic, so the outputs agree bit for bit wherever both paths use
