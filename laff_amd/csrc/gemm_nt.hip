@@ -170,6 +170,15 @@ __device__ __forceinline__ void glds_piece(unsigned off, unsigned long long sbas
 }
 
 
+// the same with the LDS base given as scalar base + constant and M0 left pointing at the piece (the lone-wave K loop: nothing else
+// in it reads M0, and every issue slot it saves is an MFMA-pipe bubble less)
+template <int IMM>
+__device__ __forceinline__ void glds_piece_s(unsigned off, unsigned long long sbase, unsigned dst_base) {
+    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(off), "s"(sbase), "s"(dst_base), "n"(IMM)
+                 : "memory", "m0");
+}
+
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long x) {     // make wave-uniformity provable
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
     return ((unsigned long long)hi << 32) | lo;
@@ -770,7 +779,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         // so LDS latency, DMA issue and barrier skew all sit under a group of MFMAs instead of in front of one.
         // The reads are inline asm (hipcc would sink them next to their uses and keep a single fragment set).
         constexpr int NR = WM + WN, NSUB = ROWB / 32;
-        u32x4 fc[2][WN], fr[2][WM];
+        // one 128x128 wave per SIMD (4-wave configurations): its own K-loop schedule below
+        constexpr bool LONE = CF::THREADS == 256 && WM * WN >= 16 && MODE != GEMM_F32 && NSUB == 4;
+        u32x4 fc[LONE ? 4 : 2][WN], fr[LONE ? 4 : 2][WM];
         auto issue = [&](int kt, int ks, int b) {
 #ifdef LAFF_ABL_NOREAD
             if (kt | ks) return;                      // ablation: fragments are read once and reused (wrong results)
@@ -785,7 +796,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         // LDS-DMA of the stage being refilled, one piece at a time: pieces [0, ITR) are the row operand, the rest the
         // column operand; `fillR/fillC/fill_sa` are the (wave-uniform) source bases and LDS slot of that stage.
         constexpr int NPIECE = CF::ITR + CF::ITC;
-        constexpr int NP0 = (NPIECE + 2) / 3, NP1 = (NPIECE - NP0 + 1) / 2, NP2 = NPIECE - NP0 - NP1;
+        // pieces issued in the barrier sub-step and in the two sub-steps behind it; a lone wave issues the whole refill in two
+        constexpr int NP0 = LONE ? (NPIECE + 1) / 2 : (NPIECE + 2) / 3;
+        constexpr int NP1 = LONE ? NPIECE - NP0 : (NPIECE - NP0 + 1) / 2;
+        constexpr int NP2 = NPIECE - NP0 - NP1;
         unsigned long long fillR = 0, fillC = 0;
         unsigned fill_sa = 0;
         bool fill_on = false;
@@ -832,6 +846,53 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
                  ...);
             }(std::make_integer_sequence<int, WM * WN>{});
         };
+        // ---- lone wave per SIMD: nothing else feeds the MFMA pipe while this wave issues anything but an MFMA, so every other
+        // instruction of the loop sits in the shadow of one (an MFMA holds the pipe for 32 cycles): the NR fragment reads of a later
+        // sub-step go one at a time behind the first NR MFMAs of the current one, the refill's DMA pieces behind the following ones
+        // (3 instructions each: glds_piece_s), and what is asked for / refilled is a compile-time property of the K-step (kstep).
+        constexpr bool ILV = LONE && WM * WN >= NR + NP0 && NP2 == 0;
+        auto issue_one = [&](int kt, int ks, int b, auto IDXC) {
+            constexpr int idx = decltype(IDXC)::value;
+            const unsigned off = (unsigned)(kt & 1) * CF::STAGEB + xk[ks];
+            const unsigned ar = laneR + off, ac = laneC + off;
+            auto& fcs = fc;
+            auto& frs = fr;
+            constexpr int ic = idx < WN ? idx : 0, ir = idx < WN ? 0 : idx - WN;
+            if constexpr (idx < WN)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fcs[b][ic]) : "v"(ac), "n"(ic * 32 * ROWB));
+            else
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(frs[b][ir]) : "v"(ar), "n"(ir * 32 * ROWB));
+        };
+        unsigned fill_base_s = 0;                       // scalar: LDS byte address of this wave's first piece of the stage being refilled
+        auto piece_s = [&](auto PC) {
+            constexpr int pc = decltype(PC)::value;
+            if constexpr (pc < CF::ITR) glds_piece_s<pc * (THREADS * 16)>(offR[pc], fillR, fill_base_s);
+            else glds_piece_s<CF::OPB_R + (pc - CF::ITR) * (THREADS * 16)>(offC[pc - CF::ITR], fillC, fill_base_s);
+        };
+        auto mfmas_ilv = [&](int b, auto RDC, int nkt_, int nks, int nb, auto P0C, auto NPC, auto DMAC) {
+            constexpr int P0 = decltype(P0C)::value, NP = decltype(NPC)::value;
+            constexpr bool rd = decltype(RDC)::value, dma = decltype(DMAC)::value;
+            static_assert(NR + NP <= WM * WN, "");
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (([&] {
+                     mfma_one(b, std::integral_constant<int, I / WN>{}, std::integral_constant<int, I % WN>{});
+                     if constexpr (I < NR) {
+                         if constexpr (rd) {
+                             __builtin_amdgcn_sched_barrier(0);
+                             issue_one(nkt_, nks, nb, std::integral_constant<int, I>{});
+                             __builtin_amdgcn_sched_barrier(0);
+                         }
+                     } else if constexpr (I < NR + NP) {
+                         if constexpr (dma) {
+                             __builtin_amdgcn_sched_barrier(0);
+                             piece_s(std::integral_constant<int, P0 + I - NR>{});
+                             __builtin_amdgcn_sched_barrier(0);
+                         }
+                     }
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, WM * WN>{});
+        };
         using IC0 = std::integral_constant<int, 0>;
         static_assert(NSUB % 2 == 0, "fragment buffer parity must repeat every K-step");
         // prologue: stage 0 landed and visible, stage 1 in flight, fragments of (K-step 0, sub-step 0) in flight
@@ -850,6 +911,76 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         unsigned long long tw_lds = 0, tw_vm = 0, tw_bar = 0;
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_readcyclecounter();
 #endif
+        if constexpr (ILV) {
+            // Fragments are asked for TWO sub-steps ahead into four register sets (a lone wave has the registers: its accumulators
+            // live in the AGPR half), the barrier sits in front of sub-step 2 (every fragment of the K-step has arrived by then, so the
+            // stage is released there) and the whole refill is issued in sub-steps 2 and 3: it has 1.5 K-steps to land.
+            // Measured at 8192^2 x 4096 (tools/debug/trace_longk.py): 2,538 cycles per K-step against 2,828 for the 8-wave loop
+            // (MFMA issue alone 2,048); waits of wave 0 per K-step: fragments 39, DMA landing 46, barrier 44 (8-wave: 39 / 86 / 782).
+            using I2 = std::integral_constant<int, NP0>;
+            using I3 = std::integral_constant<int, NP1>;
+            using T = std::true_type;
+            using F = std::false_type;
+            issue(0, 1, 1);
+            const unsigned wbase_s = __builtin_amdgcn_readfirstlane(wbase);
+            // one K-step; MORE: there is a next K-step (its first fragments are asked for here), FILL: and one after that (refilled here)
+            auto kstep = [&](int kt, auto MOREC, auto FILLC) {
+                constexpr bool more = decltype(MOREC)::value, fill = decltype(FILLC)::value;
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas_ilv(0, T{}, kt, 2, 2, IC0{}, IC0{}, F{});
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas_ilv(1, T{}, kt, 3, 3, IC0{}, IC0{}, F{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (more) {
+#ifdef LAFF_GEMM_TRACE
+                    const unsigned long long t_a = __builtin_readcyclecounter();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long t_b = __builtin_readcyclecounter();
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    const unsigned long long t_c = __builtin_readcyclecounter();
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    const unsigned long long t_d = __builtin_readcyclecounter();
+                    tw_lds += t_b - t_a; tw_vm += t_c - t_b; tw_bar += t_d - t_c;
+#else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+#endif
+                    if constexpr (fill) {                                // slot of stage kt is free now: refill it
+                        fill_base_s = lds0 + (unsigned)(kt & 1) * CF::STAGEB + wbase_s;
+                        const unsigned long long kb0 = (unsigned long long)((long)st_kin * ROWB);
+                        fillR = uniform64(curR + kb0);
+                        fillC = uniform64(curC + kb0);
+                        if (++st_kin == kt_per_seg) {                    // wave-uniform
+                            st_kin = 0;
+                            ++st_seg;
+                            curR = st_seg == 1 ? nR1 : nR2;
+                            curC = st_seg == 1 ? nC1 : nC2;
+                        }
+                    }
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas_ilv(2, MOREC, kt + 1, 0, 0, IC0{}, I2{}, FILLC);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (more) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas_ilv(3, MOREC, kt + 1, 1, 1, I2{}, I3{}, FILLC);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int kt = 0;
+            for (; kt + 2 < nkt; ++kt) {
+                if (kt == 1) TRACE(3);
+                kstep(kt, T{}, T{});
+            }
+            if (kt + 1 < nkt) { kstep(kt, T{}, F{}); ++kt; }
+            kstep(kt, F{}, F{});
+        } else {
         for (int kt = 0; kt < nkt; ++kt) {
             if (kt == 1) TRACE(3);
             // sub-steps 0 .. NSUB-2; the first two also carry the rest of the refill started at the previous barrier
@@ -904,6 +1035,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
             __builtin_amdgcn_sched_barrier(0);
             mfmas((NSUB - 1) & 1, IC0{}, std::integral_constant<int, NP0>{}, fill_on);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
 #ifdef LAFF_GEMM_TRACE
         if (a.trace && tid == 0) {
