@@ -76,6 +76,7 @@ struct Cfg {
 };
 using Cfg128 = Cfg<2, 2, 2, 2>;
 using Cfg256 = Cfg<4, 2, 2, 4>;
+using Cfg256L = Cfg<4, 4, 2, 2>;     // the same tile on 4 waves of 128x128: one 512-register wave per SIMD, for long K
 
 template <int MODE> struct ModeTraits;
 template <> struct ModeTraits<GEMM_F32> { static constexpr int ESZ = 4; };
@@ -446,13 +447,33 @@ __device__ __forceinline__ void epilogue_fc(const GemmArgs& a, f32x16 (&acc)[CF:
 // the last row are redirected to the last valid group (their rows are never used), so the arrays must be 16-byte aligned and
 // readable up to the next multiple of 16 bytes (any hipMalloc / torch allocation is).
 template <typename CF>
+__device__ __forceinline__ void band_stage_piece(const GemmArgs& a, int r0, int c0, int wave, int lane, unsigned lds0);
+
+template <typename CF>
 __device__ __forceinline__ int band_stage_rows(const GemmArgs& a, int r0, int c0, int wave, int lane, unsigned lds0) {
     constexpr int TR = CF::TR;
     const bool on = a.s_gt64 != nullptr && a.count != nullptr;
-    const unsigned dst = lds0 + (unsigned)CF::SMEM + (unsigned)ROWDATA_OFF;
     // piece w of waves 0..3: 0 = gt_col (4 rows per lane), 1 = band_r (4 rows per lane), 2/3 = s_gt64 rows [0,128) / [128,256) (2 per lane)
+    constexpr int NP = TR > 128 ? 4 : 3, NWAVES = CF::THREADS / 64;
+    if (!on) return 0;
+    if constexpr (NWAVES <= NP) {
+        // fewer waves than pieces (4-wave configurations): wave 0 also issues the piece a fifth wave would have
+        static_assert(NWAVES == NP, "row inputs: one piece per wave, the last one doubled up on wave 0");
+        if (wave == 0) band_stage_piece<CF>(a, r0, c0, NP, lane, lds0);
+        band_stage_piece<CF>(a, r0, c0, wave, lane, lds0);
+        return wave == 0 ? 2 : 1;
+    } else {
+        if (wave > NP) return 0;
+        band_stage_piece<CF>(a, r0, c0, wave, lane, lds0);
+        return 1;
+    }
+}
+
+template <typename CF>
+__device__ __forceinline__ void band_stage_piece(const GemmArgs& a, int r0, int c0, int wave, int lane, unsigned lds0) {
+    constexpr int TR = CF::TR;
     constexpr int NP = TR > 128 ? 4 : 3;
-    if (!on || wave > NP) return 0;
+    const unsigned dst = lds0 + (unsigned)CF::SMEM + (unsigned)ROWDATA_OFF;
     const int last = a.nR - 1;
     if (wave == NP) {
         // column-block band maxima: laff_rank_prepare stores them behind the per-column values at the 16-byte aligned offset
@@ -465,7 +486,7 @@ __device__ __forceinline__ int band_stage_rows(const GemmArgs& a, int r0, int c0
                      : "=&s"(keep)
                      : "v"((unsigned)g * 4u), "s"(base), "s"(__builtin_amdgcn_readfirstlane(dst + ROWDATA_BC))
                      : "memory");
-        return 1;
+        return;
     }
     if (wave < 2) {
         const int g = min(r0 + 4 * lane, last & ~3);                      // first row of this lane's group of 4
@@ -485,7 +506,6 @@ __device__ __forceinline__ int band_stage_rows(const GemmArgs& a, int r0, int c0
                      : "v"((unsigned)g * 8u), "s"(base), "s"(__builtin_amdgcn_readfirstlane(dst + ROWDATA_SG + 1024 * half))
                      : "memory");
     }
-    return 1;
 }
 
 template <bool FULL, typename CF>
@@ -900,7 +920,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         // row inputs of the banded epilogue: one extra DMA piece for waves 0..3, left in flight by this wait (see band_stage_rows)
         int extra = 0;
         if constexpr (EPI == EPI_SIM) extra = band_stage_rows<CF>(a, r0, c0, wave, lane, lds0);
-        if (extra && nkt > 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");       // wave-uniform
+        if (extra == 1 && nkt > 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");       // wave-uniform
+        else if (extra == 2 && nkt > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1493,7 +1514,7 @@ template <int MODE>
 static hipError_t launch_x3(const GemmArgs& a, hipStream_t st);
 
 int g_num_cus = 256;       // set from the device properties when a ctx is created
-int g_gemm_variant = 0;   // tuning knob LAFF_GEMM_VARIANT: 128 / 256 force the tile configuration of the 16-bit GEMM (256 also
+int g_gemm_variant = 0;   // tuning knob LAFF_GEMM_VARIANT: 128 / 256 / 512 force the tile configuration of the 16-bit GEMM (256 also
                           // keeps split products in the concatenated form); 3 forces the big tiles incl. the interleaved x3 tile
 
 template <int MODE>
@@ -1506,7 +1527,14 @@ static hipError_t launch_m(const GemmArgs& a, bool aligned, hipStream_t st) {
         const long tiles256 = (long)((a.nR + 255) / 256) * ((a.nC + 255) / 256);
         const bool big = g_gemm_variant == 256 || g_gemm_variant == 3 || (g_gemm_variant != 128 && tiles256 >= 512);
         if (big && a.nseg == 3 && g_gemm_variant != 256) return launch_x3<MODE>(a, st);
-        if (g_gemm_variant == 512) return launch_t<MODE, 2, Cfg<4, 4, 2, 2>>(a, st);      // 4 waves of 128x128 (one 512-register wave per SIMD)
+        // long K, many tiles: 4 waves of 128x128 -- 1/3 fewer LDS fragment reads per MFMA and a K loop scheduled for a lone wave per
+        // SIMD: 2,538 against 2,828 cycles per K-step at K = 4096 (tools/debug/trace_longk.py).  Its prologue and epilogue are longer
+        // (4 waves do the work of 8; the banded epilogue reads its accumulators out of the AGPR half), so it pays where the K loop
+        // dominates (tools/debug/time_shape.py, banded + S): 100k x 30k x 4096 bf16 23.5 -> 22.3 ms, count-only 21.7 -> 20.0 ms;
+        // 59,800 x 2,990 x 4096 1.54 -> 1.59 ms (not taken: 2,808 tiles); 16384^2 x 2048 1.06 -> 1.07 ms (not taken).
+        const bool lone = g_gemm_variant == 512 || (g_gemm_variant == 0 && a.nseg == 1 && tiles256 >= 4096 &&
+                                                    (long long)a.K * ModeTraits<MODE>::ESZ >= 8192);
+        if (lone) return launch_t<MODE, 2, Cfg256L>(a, st);
         if (big) return launch_t<MODE, 2, Cfg256>(a, st);
     }
     return launch_t<MODE, 2, Cfg128>(a, st);
