@@ -799,8 +799,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         // so LDS latency, DMA issue and barrier skew all sit under a group of MFMAs instead of in front of one.
         // The reads are inline asm (hipcc would sink them next to their uses and keep a single fragment set).
         constexpr int NR = WM + WN, NSUB = ROWB / 32;
-        // one 128x128 wave per SIMD (4-wave configurations): its own K-loop schedule below
-        constexpr bool LONE = CF::THREADS == 256 && WM * WN >= 16 && MODE != GEMM_F32 && NSUB == 4;
+        // the big tiles (4 waves of 128x128: one wave per SIMD; 8 waves of 128x64): the deep-prefetch K-loop schedule below
+        // (the 8-wave 256x256 tile takes the same schedule: 231 VGPRs with the four fragment sets, still two waves per SIMD; C4
+        // banded + S 0.595 -> 0.570 ms, count-only 0.457 -> 0.442 ms in back-to-back runs on one box)
+        constexpr bool LONE = ((CF::THREADS == 256 && WM * WN >= 16) || (CF::THREADS == 512 && WM * WN == 8)) && MODE != GEMM_F32 && NSUB == 4;
         u32x4 fc[LONE ? 4 : 2][WN], fr[LONE ? 4 : 2][WM];
         auto issue = [&](int kt, int ks, int b) {
 #ifdef LAFF_ABL_NOREAD
@@ -870,7 +872,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         // instruction of the loop sits in the shadow of one (an MFMA holds the pipe for 32 cycles): the NR fragment reads of a later
         // sub-step go one at a time behind the first NR MFMAs of the current one, the refill's DMA pieces behind the following ones
         // (3 instructions each: glds_piece_s), and what is asked for / refilled is a compile-time property of the K-step (kstep).
-        constexpr bool ILV = LONE && WM * WN >= NR + NP0 && NP2 == 0;
+        constexpr bool ILV = LONE && NP0 <= WM * WN && NP2 == 0;
         auto issue_one = [&](int kt, int ks, int b, auto IDXC) {
             constexpr int idx = decltype(IDXC)::value;
             const unsigned off = (unsigned)(kt & 1) * CF::STAGEB + xk[ks];
@@ -892,22 +894,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
         auto mfmas_ilv = [&](int b, auto RDC, int nkt_, int nks, int nb, auto P0C, auto NPC, auto DMAC) {
             constexpr int P0 = decltype(P0C)::value, NP = decltype(NPC)::value;
             constexpr bool rd = decltype(RDC)::value, dma = decltype(DMAC)::value;
-            static_assert(NR + NP <= WM * WN, "");
+            static_assert(NR <= WM * WN && NP <= WM * WN, "");
+            constexpr int PS = WM * WN - NP;            // pieces ride behind the last NP MFMAs (sharing a slot with a read if they must)
             [&]<int... I>(std::integer_sequence<int, I...>) {
                 (([&] {
                      mfma_one(b, std::integral_constant<int, I / WN>{}, std::integral_constant<int, I % WN>{});
-                     if constexpr (I < NR) {
-                         if constexpr (rd) {
-                             __builtin_amdgcn_sched_barrier(0);
-                             issue_one(nkt_, nks, nb, std::integral_constant<int, I>{});
-                             __builtin_amdgcn_sched_barrier(0);
-                         }
-                     } else if constexpr (I < NR + NP) {
-                         if constexpr (dma) {
-                             __builtin_amdgcn_sched_barrier(0);
-                             piece_s(std::integral_constant<int, P0 + I - NR>{});
-                             __builtin_amdgcn_sched_barrier(0);
-                         }
+                     if constexpr (I < NR && rd) {
+                         __builtin_amdgcn_sched_barrier(0);
+                         issue_one(nkt_, nks, nb, std::integral_constant<int, I>{});
+                         __builtin_amdgcn_sched_barrier(0);
+                     }
+                     if constexpr (I >= PS && dma) {
+                         __builtin_amdgcn_sched_barrier(0);
+                         piece_s(std::integral_constant<int, P0 + I - PS>{});
+                         __builtin_amdgcn_sched_barrier(0);
                      }
                  }()),
                  ...);
