@@ -622,10 +622,11 @@ __device__ __forceinline__ void epilogue_banded(const GemmArgs& a, f32x16 (&acc)
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[tr][tc][4 * q + e] * a.scale;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (4 * q + e == gi) ? sg : v[e];     // the exact score at the ground-truth entry
                     *(float4*)(slab + l31 * PITCH + tc * 32 + 8 * q + 4 * hh) = make_float4(v[0], v[1], v[2], v[3]);
                 }
+                // the exact score at the ground-truth entry: one lane of one block per row patches its slab word (a per-element select
+                // here was two of the epilogue's six vector instructions per accumulator, and the epilogue is VALU-bound)
+                if (gi >= 0) slab[l31 * PITCH + tc * 32 + 8 * (gi >> 2) + 4 * hh + (gi & 3)] = sg;
             }
         }
         int cnt = c_hi + __shfl_xor(c_hi, 32);
