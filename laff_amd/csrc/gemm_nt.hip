@@ -1214,13 +1214,14 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     const unsigned long long bRhi = (unsigned long long)((const char*)a.R + a.segR[1]), bRlo = (unsigned long long)((const char*)a.R + a.segR[0]);
     const unsigned long long bChi = (unsigned long long)((const char*)a.C + a.segC[0]), bClo = (unsigned long long)((const char*)a.C + a.segC[1]);
     unsigned long long fRhi = 0, fRlo = 0, fChi = 0, fClo = 0;     // wave-uniform source bases of the stage being filled
-    unsigned fill_sa = 0;
+    unsigned fill_sa = 0, fill_base_s = 0;
     bool fill_on = false;
     const unsigned wbase = (unsigned)(tid & ~63) * 16u;
     auto fill_begin = [&](int kt, int buf) {
         const unsigned long long kb = (unsigned long long)((long)kt * RB);
         fRhi = uniform64(bRhi + kb); fRlo = uniform64(bRlo + kb); fChi = uniform64(bChi + kb); fClo = uniform64(bClo + kb);
         fill_sa = lds0 + (unsigned)buf * CF::STAGEB;
+        fill_base_s = __builtin_amdgcn_readfirstlane(fill_sa + wbase);
         if constexpr (RF32) fX = uniform64((unsigned long long)((const char*)a.Rf) + (unsigned long long)((long)kt * (RB * 2)));
     };
     auto xload = [&]() {                         // 4 x global_load_dwordx4 (saddr form), no wait
@@ -1261,6 +1262,15 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
         const unsigned long long base = op == 0 ? (plane == 0 ? fRhi : fRlo) : (plane == 0 ? fChi : fClo);
         glds_piece(op == 0 ? offR[sub] : offC[sub], base, __builtin_amdgcn_readfirstlane(dst));
     };
+    // the same piece with the LDS address as scalar base + constant and M0 left pointing at it (3 instructions instead of 6: in the K
+    // loop every issue slot that is not an MFMA is a bubble the other wave of the SIMD has to fill)
+    auto piece_s = [&](auto PC) {
+        constexpr int pc0 = decltype(PC)::value;
+        if constexpr (RF32 && pc0 >= 4) return;
+        constexpr int pc = RF32 ? pc0 + 4 : pc0, op = pc >> 2, plane = (pc >> 1) & 1, sub = pc & 1;
+        const unsigned long long base = op == 0 ? (plane == 0 ? fRhi : fRlo) : (plane == 0 ? fChi : fClo);
+        glds_piece_s<op * CF::OPB_R + plane * CF::PLB + sub * (THREADS * 16)>(op == 0 ? offR[sub] : offC[sub], base, fill_base_s);
+    };
     auto fill_all = [&]() {
         piece(std::integral_constant<int, 0>{}); piece(std::integral_constant<int, 1>{});
         piece(std::integral_constant<int, 2>{}); piece(std::integral_constant<int, 3>{});
@@ -1286,7 +1296,8 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
         for (int t = 0; t < WM; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[set][t]) : "v"(ar), "n"(t * 32 * RB));
     };
     // WM*WN MFMAs on (fc[FS], fr[RS]) with refill pieces [P0, P0+NP) slotted in after the first NP of them
-    auto mm = [&](auto FSC, auto RSC, auto P0C, auto NPC, bool dma) {
+    auto mm = [&](auto FSC, auto RSC, auto P0C, auto NPC, auto DMAC) {
+        constexpr bool dma = decltype(DMAC)::value;
         constexpr int FS = decltype(FSC)::value, RS = decltype(RSC)::value, P0 = decltype(P0C)::value, NP = decltype(NPC)::value;
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -1298,9 +1309,9 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
                  else
                      acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fc[FS][tc]),
                                                                            __builtin_bit_cast(bf16x8, fr[RS][tr]), acc[tr][tc], 0, 0, 0);
-                 if constexpr (I < NP) {
+                 if constexpr (I < NP && dma) {
                      __builtin_amdgcn_sched_barrier(0);
-                     if (dma) piece(std::integral_constant<int, P0 + I>{});
+                     piece_s(std::integral_constant<int, P0 + I>{});
                      __builtin_amdgcn_sched_barrier(0);
                  }
              }()),
@@ -1340,63 +1351,78 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     rd_fc(1, 0, 0, 1);
     rd_fr(1, 0, 0, 0);
     XTRACE(2);
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt == 1) XTRACE(3);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            // ---- B: R_hi . C_lo (set 1); meanwhile fetch C_hi -> fc[0], R_lo -> fr[0] of this slice
-            rd_fc(0, kt, ks, 0);
-            rd_fr(0, kt, ks, 1);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            if (ks == 0) mm(I1{}, I1{}, I4{}, I2{}, fill_on);      // pieces 4,5 of the refill started at the previous barrier
-            else mm(I1{}, I1{}, I0{}, I0{}, false);
-            bool nx = true;                                        // is there a next 16-element slice?
-            int nkt_ = kt, nks = 1;
-            if (ks == 1) {
-                nx = kt + 1 < nkt;
-                nkt_ = kt + 1; nks = 0;
-                if (nx) {
-                    // every wave has read all it needs from stage kt (the fetches above have landed) and stage kt+1 has landed
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    fill_on = kt + 2 < nkt;
-                    if (fill_on) {
-                        fill_begin(kt + 2, kt & 1);
-                        if constexpr (RF32) { xload(); conv_pending = true; }
-                    }
-                }
-            }
-            // ---- C: R_hi . C_hi (fr[1], fc[0]); meanwhile fetch the next slice's C_lo -> fc[1]
-            if (nx) {
-                rd_fc(1, nkt_, nks, 1);
-                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-            }
-            if (ks == 0) mm(I0{}, I1{}, I6{}, I2{}, fill_on);      // pieces 6,7
-            else mm(I0{}, I1{}, I0{}, I2{}, fill_on);              // pieces 0,1 of the refill just started
-            if (ks == 0) fill_on = false;
-            // ---- A: R_lo . C_hi (fr[0], fc[0]); meanwhile fetch the next slice's R_hi -> fr[1]
-            if (nx) {
-                rd_fr(1, nkt_, nks, 0);
-                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            if (ks == 0) mm(I0{}, I0{}, I0{}, I0{}, false);
-            else mm(I0{}, I0{}, I2{}, I2{}, fill_on);              // pieces 2,3
-            if constexpr (RF32) {
-                if (ks == 0 && conv_pending) {
-                    // the X loads are older than the four column-operand pieces issued since: vmcnt(4) = "X has landed"
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt vmcnt(4)" : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[1][0]), "+v"(xs[1][1])::"memory");
-                    xconvert();
-                    __builtin_amdgcn_sched_barrier(0);
-                    conv_pending = false;
-                }
-            }
+    // one K-step with its place in the loop as compile-time properties -- MORE: there is a next K-step (barrier, first fetches from its
+    // stage); FILL: and one after that (its refill starts at this K-step's barrier: pieces 0..3 here, 4..7 in the next K-step, which
+    // therefore has PREV); with RF32, MORE also means "the X rows of the next K-step are waiting to be converted".  The peeled head /
+    // tail leave no per-slot scalar branch in the steady-state K-step.
+    using T = std::true_type;
+    using F = std::false_type;
+    auto kstep = [&](int kt, auto MOREC, auto FILLC, auto PREVC) {
+        constexpr bool more = decltype(MOREC)::value, fill = decltype(FILLC)::value;
+        // ======== slice 0
+        // ---- B: R_hi . C_lo (set 1); meanwhile fetch C_hi -> fc[0], R_lo -> fr[0] of this slice
+        rd_fc(0, kt, 0, 0);
+        rd_fr(0, kt, 0, 1);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        mm(I1{}, I1{}, I4{}, I2{}, PREVC);                         // pieces 4,5 of the refill started at the previous barrier
+        // ---- C: R_hi . C_hi (fr[1], fc[0]); meanwhile fetch slice 1's C_lo -> fc[1]
+        rd_fc(1, kt, 1, 1);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        mm(I0{}, I1{}, I6{}, I2{}, PREVC);                         // pieces 6,7
+        // ---- A: R_lo . C_hi (fr[0], fc[0]); meanwhile fetch slice 1's R_hi -> fr[1]
+        rd_fr(1, kt, 1, 0);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        mm(I0{}, I0{}, I0{}, I0{}, F{});
+        if constexpr (RF32 && more) {
+            // the X loads are older than the four column-operand pieces issued since: vmcnt(4) = "X has landed"
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(xs[0][0]), "+v"(xs[0][1]), "+v"(xs[1][0]), "+v"(xs[1][1])::"memory");
+            xconvert();
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // ======== slice 1
+        rd_fc(0, kt, 1, 0);
+        rd_fr(0, kt, 1, 1);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        mm(I1{}, I1{}, I0{}, I0{}, F{});
+        if constexpr (more) {
+            // every wave has read all it needs from stage kt (the fetches above have landed) and stage kt+1 has landed
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (fill) {
+                fill_begin(kt + 2, kt & 1);
+                if constexpr (RF32) xload();
+            }
+            rd_fc(1, kt + 1, 0, 1);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        }
+        mm(I0{}, I1{}, I0{}, I2{}, FILLC);                         // pieces 0,1 of the refill just started
+        if constexpr (more) {
+            rd_fr(1, kt + 1, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        mm(I0{}, I0{}, I2{}, I2{}, FILLC);                         // pieces 2,3
+    };
+    {
+        int kt = 0;
+        if (nkt >= 3) {
+            kstep(0, T{}, T{}, F{});
+            for (kt = 1; kt + 2 < nkt; ++kt) {
+                if (kt == 1) XTRACE(3);
+                kstep(kt, T{}, T{}, T{});
+            }
+            kstep(kt, T{}, F{}, T{});
+            ++kt;
+        } else if (nkt == 2) {
+            kstep(0, T{}, F{}, F{});
+            kt = 1;
+        }
+        kstep(kt, F{}, F{}, F{});
     }
 
     XTRACE(4);
