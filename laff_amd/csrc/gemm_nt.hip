@@ -171,14 +171,22 @@ __device__ __forceinline__ void glds_piece(unsigned off, unsigned long long sbas
 }
 
 
-// the same with the LDS base given as scalar base + constant and M0 left pointing at the piece (the lone-wave K loop: nothing else
-// in it reads M0, and every issue slot it saves is an MFMA-pipe bubble less)
+// the same with the LDS base given as scalar base + constant and M0 LEFT pointing at the piece: 3 instructions instead of 6 (every
+// issue slot saved in the K loop is an MFMA-pipe bubble less).  M0 is a reserved register the compiler does not track through an
+// asm statement, so the K loops that use this bracket themselves with m0_save() / m0_restore(); nothing the compiler generates
+// inside them reads M0 (their only LDS-DMA is this helper).
 template <int IMM>
 __device__ __forceinline__ void glds_piece_s(unsigned off, unsigned long long sbase, unsigned dst_base) {
     asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :: "v"(off), "s"(sbase), "s"(dst_base), "n"(IMM)
-                 : "memory", "m0");
+                 : "memory");
 }
+__device__ __forceinline__ unsigned m0_save() {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep)::"memory");
+    return keep;
+}
+__device__ __forceinline__ void m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory"); }
 
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long x) {     // make wave-uniformity provable
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
@@ -995,6 +1003,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
                 mfmas_ilv(3, MOREC, kt + 1, 1, 1, I2{}, I3{}, FILLC);
                 __builtin_amdgcn_sched_barrier(0);
             };
+            const unsigned m0_keep = m0_save();
             int kt = 0;
             for (; kt + 2 < nkt; ++kt) {
                 if (kt == 1) TRACE(3);
@@ -1002,6 +1011,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int r0, const
             }
             if (kt + 1 < nkt) { kstep(kt, T{}, F{}); ++kt; }
             kstep(kt, F{}, F{});
+            m0_restore(m0_keep);
         } else {
         for (int kt = 0; kt < nkt; ++kt) {
             if (kt == 1) TRACE(3);
@@ -1199,7 +1209,6 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     u32x4 xs[2][2];
     unsigned long long fX = 0;
     unsigned x_sa = 0;                                            // LDS slot the staged values go to
-    bool conv_pending = false;
     if constexpr (RF32) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -1215,7 +1224,6 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     const unsigned long long bChi = (unsigned long long)((const char*)a.C + a.segC[0]), bClo = (unsigned long long)((const char*)a.C + a.segC[1]);
     unsigned long long fRhi = 0, fRlo = 0, fChi = 0, fClo = 0;     // wave-uniform source bases of the stage being filled
     unsigned fill_sa = 0, fill_base_s = 0;
-    bool fill_on = false;
     const unsigned wbase = (unsigned)(tid & ~63) * 16u;
     auto fill_begin = [&](int kt, int buf) {
         const unsigned long long kb = (unsigned long long)((long)kt * RB);
@@ -1345,7 +1353,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
     asm volatile("" ::: "memory");
     if (nkt > 1) {
         fill_begin(1, 1);
-        if constexpr (RF32) { xload(); conv_pending = true; }
+        if constexpr (RF32) xload();
         fill_all();
     }
     rd_fc(1, 0, 0, 1);
@@ -1409,6 +1417,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
         mm(I0{}, I0{}, I2{}, I2{}, FILLC);                         // pieces 2,3
     };
     {
+        const unsigned m0_keep = m0_save();
         int kt = 0;
         if (nkt >= 3) {
             kstep(0, T{}, T{}, F{});
@@ -1423,6 +1432,7 @@ __device__ __forceinline__ void gemm_tile_x3(const GemmArgs& a, const int r0, co
             kt = 1;
         }
         kstep(kt, F{}, F{}, F{});
+        m0_restore(m0_keep);
     }
 
     XTRACE(4);
