@@ -194,6 +194,11 @@ __global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
         n = it / a.H;
         h = (int)(it - n * a.H);
     }
+    // one item per wavefront: (n, h) are wave-uniform, but derived from threadIdx they look divergent to the compiler -- pinned to
+    // scalars, every row base (src + n * ld, E + item * d, ...) becomes SALU work and the loads take the scalar-base + 32-bit lane
+    // offset form: the 64-bit address VALU (a tenth of this VALU-bound kernel's vector instructions) disappears
+    n = ((long)__builtin_amdgcn_readfirstlane((int)(n >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)n);
+    h = __builtin_amdgcn_readfirstlane(h);
     const long item = n * a.H + h;
     const int d = a.d;
 
