@@ -9,7 +9,12 @@ One "step" = one full pass of the hot path over the synthetic workload with ever
 score matrix -> ground-truth rank counts -> R@K / MedR / mAP on the host.  Default workload: BASELINE.json's headline
 shape, 40k texts x 10k videos x (4+4 features of 512-d), one head of d = 512 (`configs[3]`; it fits one GPU).
 With N > 1 the SAME total problem is sharded by video rows (strong scaling) with one RCCL all-gather of the text
-operand (laff_amd/dist.py).  Rank 0 prints ONE JSON line.
+embeddings (laff_amd/dist.py: the loop being sharded is /root/reference/model/model.py:1057-1077).  Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no launcher environment (no RANK / WORLD_SIZE): this process -- which has not touched the GPU -- starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process, forwards rank 0's
+JSON line to its own stdout and exits with the child's code.  LAFF_BENCH_DRYRUN=1 runs the same launch + collective path on CPU
+(gloo, oracle-backed stand-in kernels from tests/dist_util.py, a toy problem): what the CPU test of the self-launch uses.
 """
 import argparse
 import json
@@ -133,8 +138,8 @@ def cpu_baseline(workload, sample_nt, sample_nv, heads, d, seed, spec=None):
         cores = os.cpu_count()
     main = {'value': sample_nt * sample_nv / dt, 'unit': 'pairs/s', 'cores': cores, 'host_cores': os.cpu_count(), 'kind': 'port',
             'sample': '%dx%d slice of the same synthetic workload (seed, generator, weights), numpy oracle in the reference\'s '
-                      'batch-64 block-loop shape (towers + per-block cosine), ranks by counting, %.1f s on the GPU box host'
-                      % (sample_nt, sample_nv, dt),
+                      'batch-64 block-loop shape (towers + per-block cosine), ranks by counting, %.1f s on the GPU box host '
+                      '(%d BLAS threads of %d host cores)' % (sample_nt, sample_nv, dt, cores, os.cpu_count()),
             'r1': metrics[0]}
     # BASELINE.md section 3 variants.  (a) reference-shaped INCLUDING its ranking stage: full-matrix argsort + the per-query label loop
     # + evaluation.eval on the label matrix (predictor.py:232-246), on a row sample (the label matrix alone is 8 B per pair);
@@ -171,6 +176,96 @@ def cpu_baseline(workload, sample_nt, sample_nv, heads, d, seed, spec=None):
     return main
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(n, argv):
+    """Parent of a `--gpus N` run without a launcher: N ranks under torch.distributed.run as a child process (never an exec: this
+    image refuses to replace a process image once anything may have initialised the GPU), rank 0's line relayed."""
+    import subprocess
+    dry = os.environ.get('LAFF_BENCH_DRYRUN') == '1'
+    if not dry:
+        have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if have < n:
+            print('bench.py: --gpus %d but this node has %d visible GPU(s)' % (n, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL's peer mappings fail without it on this driver
+    env.setdefault('OMP_NUM_THREADS', '8' if not dry else '2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.lstrip().startswith('{') and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)                 # anything else a rank printed to fd 1
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print('bench.py: the ranks exited 0 without printing a JSON line', file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def dryrun_main(args):
+    """LAFF_BENCH_DRYRUN=1: the launch / rendezvous / collective / timing / reporting path of an N-rank run on CPU -- gloo instead
+    of RCCL, the oracle-backed stand-in of the per-rank kernels (tests/dist_util.py) on a toy problem.  Not a measurement."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from dist_util import OracleBackend, problem
+    from laff_amd.dist import evaluate_sharded, evaluate_sharded_by_text, shard_bounds
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if world > 1:
+        dist.init_process_group('gloo')
+    xt, xv, gt, Wt, Wv = problem()
+    Nt, Nv = len(xt), len(xv)
+    t0, t1 = shard_bounds(Nt, world, rank)
+    v0, v1 = shard_bounds(Nv, world, rank)
+    be = OracleBackend(Wt, Wv)
+    vis_l, txt_l, gt_t = {'x': torch.from_numpy(xv[v0:v1])}, {'x': torch.from_numpy(xt[t0:t1])}, torch.from_numpy(gt)
+    out = {}
+    for kind, fn in (('video', evaluate_sharded), ('text', evaluate_sharded_by_text)):
+        for _ in range(max(1, args.warmup)):
+            res = fn(be, vis_l, txt_l, gt_t, Nt, Nv, 1)
+        if world > 1:
+            dist.barrier()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            res = fn(be, vis_l, txt_l, gt_t, Nt, Nv, 1)
+        if world > 1:
+            dist.barrier()
+        el = torch.tensor([time.perf_counter() - ts], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        out[kind] = (float(el.item()), res)
+    if rank == 0:
+        el, res = out['video']
+        m = res['metrics']
+        line = {'metric': 'text-video cosine pairs/sec', 'value': float(Nt) * Nv * args.steps / el, 'unit': 'pairs/s', 'n_gpus': world,
+                'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                'dtype': 'dry run (numpy oracle stand-in)', 'data': 'synthetic',
+                'config': {'workload': 'DRYRUN %d texts x %d videos (CPU, gloo): exercises the launcher, not the kernels' % (Nt, Nv),
+                           'shard': 'video', 'backend': 'gloo'},
+                'alt_shard': {'shard': 'text', 'ms_per_step': 1e3 * out['text'][0] / args.steps,
+                              'ranks_equal': bool(torch.equal(out['text'][1]['ranks'], res['ranks']))},
+                'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3]}, 'collective_ms': None,
+                'roofline': None, 'cpu_baseline': None}
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -181,10 +276,11 @@ def main():
     ap.add_argument('--fc-precision', default='fp16x3', help="FC projections: fp32 (fp32 MFMA) | fp16x3 (exact fp16 hi/lo split)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of HIP-graph replays')
-    ap.add_argument('--shard', default='auto', choices=['auto', 'video', 'text'],
-                    help="N > 1 decomposition: 'video' (BASELINE.json: video-row shards, all-gather of the text embeddings, two small "
-                         "all-reduces), 'text' (text-row shards, all-gather of the video embeddings, no all-reduce) or 'auto' = the one "
-                         "that gathers fewer rows (laff_amd.dist.choose_sharding)")
+    ap.add_argument('--shard', default='video', choices=['auto', 'video', 'text'],
+                    help="N > 1 decomposition of the headline number: 'video' (default; BASELINE.json: video-row shards, all-gather of "
+                         "the text embeddings, two small all-reduces), 'text' (text-row shards, all-gather of the video embeddings, no "
+                         "all-reduce) or 'auto' = the one that gathers fewer rows (laff_amd.dist.choose_sharding).  The other scheme is "
+                         "timed too and reported beside it (alt_shard)")
     ap.add_argument('--two-streams', action='store_true', help='single GPU: alternate the two captured steps between two streams')
     ap.add_argument('--no-extra-modes', action='store_true', help='skip the sustained loop and the count-only mode (profiling runs)')
     ap.add_argument('--sustain-seconds', type=float, default=2.0, help='extra untimed-by-the-driver loop reporting the sustained rate')
@@ -192,6 +288,12 @@ def main():
     ap.add_argument('--profile-steps', type=int, default=5, help='eager steps (after the timed region) for per-kernel events')
     ap.add_argument('--seed', type=int, default=1237)
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        # no launcher: become the parent of N ranks (nothing in this process has touched the GPU yet)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if os.environ.get('LAFF_BENCH_DRYRUN') == '1':
+        return dryrun_main(args)
 
     # stdout carries ONE line (the JSON): native libraries print banners to fd 1 (RCCL's version block at communicator teardown), so
     # fd 1 is pointed at stderr for the whole run and the line is written to the saved descriptor
@@ -249,11 +351,11 @@ def main():
 
     pins = [metrics_pinned, torch.zeros(8, dtype=torch.float64).pin_memory()]
 
-    def step(timed, async_metrics=False, runner=None, state=None, slot=0, want_scores=True):
+    def step(timed, async_metrics=False, runner=None, state=None, slot=0, want_scores=True, kind=None):
         timer.enabled = timed
         prof.enabled = timed
         timer.start()
-        if shard == 'text' and distributed:
+        if (kind or shard) == 'text' and distributed:
             return evaluate_sharded_by_text(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer, want_scores=want_scores,
                                             metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
                                             force_collectives=force_dist, finish_tag=str(slot))
@@ -329,6 +431,35 @@ def main():
             return r
         return step(True)        # eager: per-launch events are recorded inside the timed region
 
+    def dist_loop(kind, runner_, state_):
+        """K steps of one N > 1 decomposition, two in flight at most; returns the wall time (barrier + sync on both sides, MAX over ranks)."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        ev = [torch.cuda.Event(), torch.cuda.Event()]
+        for k in range(args.steps):
+            if runner_ is not None:
+                step(False, async_metrics=True, runner=runner_, state=state_, slot=k % 2, kind=kind)
+                ev[k % 2].record()
+                if k:
+                    ev[(k - 1) % 2].synchronize()
+                    check_metrics_flag(pins[(k - 1) % 2])
+            else:
+                step(False, kind=kind)
+        torch.cuda.synchronize()
+        if runner_ is not None:
+            check_metrics_flag(pins[(args.steps - 1) % 2])
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - ts
+        if world > 1:
+            tt_ = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            el = float(tt_.item())
+        return el
+
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -373,7 +504,10 @@ def main():
     if graph is not None or runner is not None:
         final_metrics = tuple(pins[(args.steps - 1) % 2][:7].tolist())
         # per-kernel durations: the same kernels on the same data, launched eagerly with events around each launch
-        # (every rank runs the same number of steps: the collectives stay matched)
+        # (every rank runs the same number of steps: the collectives stay matched).  One eager step first, without events: it
+        # re-allocates what the graphs' private pools held and would otherwise sit in the averages as a host-bound outlier
+        res = step(False)
+        torch.cuda.synchronize()
         for _ in range(args.profile_steps):
             res = step(True)
         torch.cuda.synchronize()
@@ -381,6 +515,27 @@ def main():
     else:
         final_metrics = res['metrics']
         prof_steps = args.steps
+
+    # the other N > 1 decomposition, timed the same way, reported beside the headline one
+    alt = None
+    if distributed:
+        other = 'text' if shard == 'video' else 'video'
+        try:
+            r2, s2 = None, {}
+            if runner is not None:
+                from laff_amd.dist import GraphRunner
+                r2 = GraphRunner()
+                for slot in (0, 1):
+                    step(False, async_metrics=True, runner=r2, state=s2, slot=slot, kind=other)
+                    torch.cuda.synchronize()
+            else:
+                step(False, kind=other)
+            el2 = dist_loop(other, r2, s2)
+            alt = {'shard': other, 'ms_per_step': 1e3 * el2 / args.steps, 'value': float(Nt) * Nv * args.steps / el2,
+                   'R@1': float(pins[(args.steps - 1) % 2][0]) if r2 is not None else None}
+            del r2, s2
+        except Exception as e:  # noqa: BLE001  (every rank takes the same path: the collectives stay matched)
+            alt = {'shard': other, 'error': str(e)}
 
     sustained, no_scores = None, None
     if graph is not None and world == 1 and not distributed and not args.no_extra_modes:
@@ -551,7 +706,7 @@ def main():
             del Ss, Ts, Vs, t3, v3
         line = {
             'metric': 'text-video cosine pairs/sec', 'value': pairs / elapsed * args.steps, 'unit': 'pairs/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
+            'n_gpus': world, 'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32 towers (FC on %s) + %s similarity' % ('fp32 MFMA' if args.fc_precision == 'fp32' else 'fp16 hi/lo split x3 MFMA', args.precision),
             'data': 'synthetic',
             'config': {'workload': '%s: %d texts x %d videos, %s, %d head(s) x d=%d' % (
@@ -569,6 +724,10 @@ def main():
                        'launch': launch_mode},
             'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6],
                         'vs_strict_similarity': agreement},
+            # per-step time this rank's stream spent in / waiting on each collective (eager pass, HIP events around the call)
+            'collective_ms': ({k: round(stages[k], 4) for k in ('all_gather_wait', 'allreduce_s_gt', 'allreduce_count', 'allgather_ranks')
+                               if k in stages} if distributed else None),
+            'alt_shard': alt,
             'stages_ms_eager_pass': {k: round(v, 4) for k, v in stages.items()},   # host-issued launches with events: longer than a graph step
             'sustained': sustained,
             'no_scores_mode': no_scores,

@@ -52,7 +52,10 @@ enum {
 /* operand precision of the similarity GEMM */
 enum {
     LAFF_PREC_FP32 = 0,    /* fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an fp32 fma chain          */
-    LAFF_PREC_FP16 = 1,    /* one fp16 MFMA pass: max |d cos| ~ 7e-5 at d=512 (inside the 1e-4 contract) */
+    LAFF_PREC_FP16 = 1,    /* one fp16 MFMA pass: MEASURED max |d cos| 8e-5 on 4e8 pairs at d=512; the PROVEN per-pair bound is
+                            * band_t + band_v of laff_rank_prepare, 4-5e-4 at d=512 (Cauchy-Schwarz on the operand rounding).  Ranks
+                            * from the banded pipeline are exact regardless; a caller that needs every returned score inside 1e-4
+                            * takes FP16X3 (what predict() / retrieve() default to) */
     LAFF_PREC_BF16 = 2,    /* one bf16 MFMA pass: ~5e-4 -- for rank-identity workloads only              */
     LAFF_PREC_FP16X3 = 3,  /* fp16 hi+lo split, 3 MFMA passes: ~1e-7                                    */
     LAFF_PREC_BF16X3 = 4   /* bf16 hi+lo split, 3 MFMA passes: ~1e-6                                    */
@@ -253,8 +256,9 @@ int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv,
  *                          S (nullable) receives (float)s_gt64 at the ground-truth entry.
  *   laff_rank_resolve      re-scores the listed pairs: count[row] += exact > s_gt64[row]; S (nullable) takes the fp32 value of the
  *                          exact score (one ulp above (float)s_gt64 where rounding would hide a strict inequality) so that ranks
- *                          recounted from S equal count + 1.  More than pair_cap pairs: pairs[1] = 1 and count[0] is poisoned
- *                          (negative), which trips the rank < 1 flag of laff_rank_metrics*.
+ *                          recounted from S equal count + 1.  pair_cap is used in whole groups of four slots (rounded down, >= 4).
+ *                          More than pair_cap pairs: pairs[1] = 1 and count[0] is poisoned with -(2^26) -- negative even after an
+ *                          int32 all-reduce SUM over <= 16 shards -- which trips the rank < 1 flag of laff_rank_metrics*.
  * After laff_rank_resolve (and an all-reduce SUM of count when videos are sharded) count + 1 are the exact ranks. */
 int laff_rank_prepare(laff_ctx* ctx, const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
                       int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t, float* band_v,

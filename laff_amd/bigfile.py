@@ -12,16 +12,23 @@ import numpy as np
 
 class BigFile:
     def __init__(self, datadir, bin_file='feature.bin'):
-        self.nr_of_images, self.ndims = list(map(int, open(os.path.join(datadir, 'shape.txt')).readline().split()))
-        id_file = os.path.join(datadir, 'id.txt')
-        self.names = open(id_file, 'r').read().strip().split('\n')
-        if len(self.names) != self.nr_of_images:
-            self.names = open(id_file, 'r').read().strip().split(' ')
-        assert len(self.names) == self.nr_of_images
-        self.name2index = dict(zip(self.names, range(self.nr_of_images)))
+        with open(os.path.join(datadir, 'shape.txt')) as fh:
+            rows, width = (int(tok) for tok in fh.readline().split())
+        with open(os.path.join(datadir, 'id.txt')) as fh:
+            body = fh.read().strip()
+        # one id per line, or (older feature directories) all ids on one line separated by blanks: the separator that yields
+        # `rows` ids is the right one
+        for sep in ('\n', ' '):
+            ids = body.split(sep)
+            if len(ids) == rows:
+                break
+        else:
+            raise AssertionError('%s: id.txt holds %d ids, shape.txt says %d' % (datadir, len(ids), rows))
+        self.nr_of_images, self.ndims, self.names = rows, width, ids
+        self.name2index = {name: i for i, name in enumerate(ids)}     # a repeated id resolves to its LAST row, as dict(zip()) does
         self.binary_file = os.path.join(datadir, bin_file)
         self._mm = None
-        print('[%s] %dx%d instances loaded from %s' % (self.__class__.__name__, self.nr_of_images, self.ndims, datadir))
+        print('[%s] %dx%d instances loaded from %s' % (type(self).__name__, rows, width, datadir))
 
     def _matrix(self):
         if self._mm is None:
@@ -29,15 +36,15 @@ class BigFile:
         return self._mm
 
     def _resolve(self, requested, isname=True):
-        requested = set(requested)
+        """De-duplicated (row, id) hits in file order; unknown ids are dropped, out-of-range rows are an AssertionError."""
+        wanted = set(requested)
         if isname:
-            pairs = [(self.name2index[x], x) for x in requested if x in self.name2index]
-        else:
-            assert min(requested) >= 0
-            assert max(requested) < len(self.names)
-            pairs = [(x, self.names[x]) for x in requested]
-        pairs.sort(key=lambda v: v[0])
-        return pairs
+            known = self.name2index
+            return sorted((known[n], n) for n in wanted if n in known)          # rows are unique: the id never decides the order
+        rows = sorted(wanted)
+        if rows and not (0 <= rows[0] and rows[-1] < len(self.names)):
+            raise AssertionError('row index outside [0, %d)' % len(self.names))
+        return [(r, self.names[r]) for r in rows]
 
     def read(self, requested, isname=True):
         pairs = self._resolve(requested, isname)

@@ -537,8 +537,9 @@ static int sim_gemm_impl(laff_ctx* ctx, const char* who, const void* T, const vo
     if (S && lds < Nv) return fail(LAFF_E_SHAPE, "%s: lds=%d < Nv=%d", who, lds, Nv);
     if (gt_col && !count) return fail(LAFF_E_ARG, "%s: gt_col needs count", who);
     if (gt_col && !s_gt && !s_gt64) return fail(LAFF_E_ARG, "%s: gt_col needs the ground-truth scores", who);
-    if (s_gt64 && (!gt_col || !band_t || !band_v || !pairs || pair_cap < 1))
-        return fail(LAFF_E_ARG, "%s: the banded count needs gt_col, band_t, band_v and a pair list", who);
+    pair_cap &= ~3u;            /* the resolve kernel reads the list four slots at a time: a ragged tail is never used */
+    if (s_gt64 && (!gt_col || !band_t || !band_v || !pairs || pair_cap < 4))
+        return fail(LAFF_E_ARG, "%s: the banded count needs gt_col, band_t, band_v and a pair list of >= 4 slots", who);
     if (!aligned16(T) || !aligned16(V)) return fail(LAFF_E_ALIGN, "%s: operands must be 16-byte aligned", who);
     if (s_gt64 && (!aligned16(gt_col) || !aligned16(s_gt64) || !aligned16(band_t) || !aligned16(band_v)))
         return fail(LAFF_E_ALIGN, "%s: gt_col, s_gt64, band_t and band_v must be 16-byte aligned (fetched in 16-byte groups)", who);
@@ -606,7 +607,8 @@ int laff_rank_resolve(laff_ctx* ctx, const float* Et, const float* Ev, int Nt, i
     CHECK_CTX(ctx);
     if (Nt == 0 || Nv == 0) return LAFF_OK;                 /* empty problem: nothing was listed */
     if (!Et || !Ev || !s_gt64 || !count || !pairs) return fail(LAFF_E_ARG, "laff_rank_resolve: null argument");
-    if (Nt < 0 || Nv < 0 || H < 1 || d < 4 || (d & 3) || pair_cap < 1) return fail(LAFF_E_SHAPE, "laff_rank_resolve: bad shape");
+    pair_cap &= ~3u;            /* as laff_sim_gemm_banded: whole groups of four slots */
+    if (Nt < 0 || Nv < 0 || H < 1 || d < 4 || (d & 3) || pair_cap < 4) return fail(LAFF_E_SHAPE, "laff_rank_resolve: bad shape");
     if (S && lds < Nv) return fail(LAFF_E_SHAPE, "laff_rank_resolve: lds=%d < Nv=%d", lds, Nv);
     if (!aligned16(Et) || !aligned16(Ev)) return fail(LAFF_E_ALIGN, "laff_rank_resolve: embeddings must be 16-byte aligned");
     DeviceGuard g(ctx->device);

@@ -361,7 +361,7 @@ hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, 
 // pairs appended with the counter.  A 16-lane group walks a segment until the first invalid slot; the overflow region is shared out
 // four pairs per wavefront at a time.  count[row] += 1 when the exact score beats the exact ground-truth score; S (optional) takes the fp32 value of the
 // exact score, nudged by one ulp where rounding to fp32 would hide a strict inequality, so that ranks recounted from S
-// (laff_rank_count) equal the ranks produced here.  More pairs than the list holds: overflow flag + count[0] poisoned (rank < 1 trips
+// (laff_rank_count) equal the ranks produced here.  More pairs than the list holds: overflow flag + count[0] poisoned with -(2^26) (rank < 1 trips
 // the error flag of laff_rank_metrics*).
 __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d,
                                                            const double* __restrict__ s_gt64, int* __restrict__ count,
@@ -372,7 +372,9 @@ __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restri
     const unsigned n_over = pairs[0], regA = pairs[2];
     const unsigned long long room = pair_cap > regA ? pair_cap - regA : 0u;
     if (n_over > room) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[1] = 1u; count[0] = -0x40000000; }
+        // the poison survives an int32 all-reduce(SUM) over up to 16 shards (laff_amd/dist.py 'video' scheme): 16 * -(2^26) = -2^30 does
+        // not wrap, and no legitimate count (< 2^26 videos) lifts it back above zero
+        if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[1] = 1u; count[0] = -(1 << 26); }
     }
     auto one = [&](unsigned r, unsigned c, bool ok) {
         const double ex = exact_cos(Et + (long)r * K, Ev + (long)c * K, H, d, sl);

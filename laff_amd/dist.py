@@ -268,13 +268,17 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
                 T = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
             return compute.prepare(Et, vis_emb, T, V_local, gt, v0)
         st = run('prep', prep_phase)
+        mark('prep')
         if comm:
             dist.all_reduce(compute.s_gt_of(st), op=dist.ReduceOp.MAX, group=group)
-        mark('s_gt')
+            mark('allreduce_s_gt')
         S_local, count = run('sim', lambda: compute.sim_ranked(st, want_scores))
         mark('sim_gemm')
         if comm:
+            # an overflowing pair list poisons count[0] with -(2^26) on every rank it happens on (rank.hip: rank_resolve_kernel); the
+            # SUM of up to 16 such poisons stays negative, so the rank < 1 flag of the metrics kernel still trips after the reduction
             dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
+            mark('allreduce_count')
 
         metrics = None
         if hasattr(compute, 'finish') and (metrics_out is not None or want_metrics):
@@ -342,11 +346,12 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
             gathered = state['gathered_v']
             dist.all_gather_into_tensor(gathered, send, group=group)
         mark('all_gather_wait')
-        # this rank's slice of the ground-truth columns lives in `state`: a captured phase reads it at a fixed address on every replay
-        key = (gt.data_ptr(), t0, t1)
-        if state.get('gt_local_key') != key:
-            state['gt_local_key'], state['gt_local'] = key, gt[t0:t1].contiguous()
+        # this rank's slice of the ground-truth columns lives in `state`: a captured phase reads it at a fixed address on every
+        # replay, and it is refreshed from `gt` on every step (outside the captured phase) like the 'video' scheme reads gt live
+        if 'gt_local' not in state or state['gt_local'].numel() != t1 - t0 or state['gt_local'].device != gt.device:
+            state['gt_local'] = torch.empty(t1 - t0, dtype=gt.dtype, device=gt.device)
         gt_local = state['gt_local']
+        gt_local.copy_(gt[t0:t1])
 
         def rank_phase():
             if comm:
@@ -369,6 +374,7 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
                 state['gathered_r'] = torch.empty(world * tmax, dtype=torch.int32, device=mine.device)
             all_ranks = state['gathered_r']
             dist.all_gather_into_tensor(all_ranks, mine, group=group)
+            mark('allgather_ranks')
         else:
             all_ranks = mine
 

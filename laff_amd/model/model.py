@@ -683,10 +683,25 @@ class W2VVPP(nn.Module):
                 except (IndexError, ValueError, AttributeError):
                     owner = None                 # ids do not follow the protocol: plain scores
             if owner is not None:
-                T = ops.pack_rows(to_device_and_float16(txt_all).contiguous(), True, 1e-13, precision)
-                V = ops.pack_rows(to_device_and_float16(vis_used).contiguous(), True, 1e-13, precision)
-                gt = torch.as_tensor(owner, dtype=torch.int32, device=T.buf.device)
-                S, count, _ = ops.exact_ranks(txt_all.contiguous(), vis_used.contiguous(), T, V, gt)
+                gt = torch.as_tensor(owner, dtype=torch.int32, device=txt_all.device)
+                Et, Ev = txt_all.contiguous(), vis_used.contiguous()
+                # The pair list of the exact-rank pipeline overflows only on degenerate scores (thousands of videos inside one
+                # query's error band).  This path goes to the host anyway, so the flag is read (one small synchronising copy) and
+                # the pass repeated: first with an 8x larger list, then with hi/lo split operands (band ~1e-6 instead of ~4e-4).
+                # Nothing is published from an overflowed pass.
+                attempts = [(precision, None), (precision, 8 * ops.default_pair_cap(Et.shape[0]))]
+                if precision not in ('fp16x3', 'bf16x3'):
+                    attempts.append(('fp16x3', 8 * ops.default_pair_cap(Et.shape[0])))
+                for prec, cap in attempts:
+                    T = ops.pack_rows(to_device_and_float16(Et), True, 1e-13, prec)
+                    V = ops.pack_rows(to_device_and_float16(Ev), True, 1e-13, prec)
+                    S, count, st = ops.exact_ranks(Et, Ev, T, V, gt, pair_cap=cap)
+                    if not st.listed_pairs()[1]:
+                        break
+                    del S, count, st
+                else:
+                    raise RuntimeError('laff_amd: the pair list of the exact-rank pipeline overflowed even with split operands and an 8x '
+                                       'list (%d texts x %d videos): the scores are degenerate' % (Et.shape[0], Ev.shape[0]))
                 self.last_t2v_ranks = count + 1
             else:
                 S = self.get_txt2vis_matrix(txt_all, vis_used, measure, precision)

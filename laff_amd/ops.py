@@ -546,7 +546,9 @@ def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None):
     if gt_col.data_ptr() % 16:          # the GEMM fetches gt_col in 16-byte groups
         gt_col = gt_col.clone()
     dev = Et.device
-    cap = int(pair_cap) if pair_cap is not None else default_pair_cap(Nt)
+    cap = (int(pair_cap) if pair_cap is not None else default_pair_cap(Nt)) & ~3      # the list is used in groups of four slots
+    if cap < 4:
+        raise ValueError('pair_cap must be >= 4')
     s_gt64 = torch.empty((Nt + 2,), device=dev, dtype=torch.float64)[:Nt]
     band_t = torch.empty((Nt + 4,), device=dev, dtype=torch.float32)          # (+ slack: the GEMM fetches 16-byte groups)
     band_v = torch.empty((((Nv + 3) & ~3) + (Nv + 63) // 64 + 4,), device=dev, dtype=torch.float32)     # per column, then (16-byte aligned) per 64-column block
@@ -587,9 +589,10 @@ def rank_resolve(st, S=None):
     return st.count
 
 
-def exact_ranks(Et, Ev, T, V, gt_col, want_scores=True, col0=0):
-    """prepare -> banded GEMM -> resolve on one device.  Returns (S or None, count int32 (Nt,), RankState); ranks = count + 1."""
-    st = rank_prepare(Et, Ev, T, V, gt_col, col0)
+def exact_ranks(Et, Ev, T, V, gt_col, want_scores=True, col0=0, pair_cap=None):
+    """prepare -> banded GEMM -> resolve on one device.  Returns (S or None, count int32 (Nt,), RankState); ranks = count + 1.
+    An overflowing pair list (state.listed_pairs()[1]) poisons count[0]: rank_metrics(base=1) raises on it."""
+    st = rank_prepare(Et, Ev, T, V, gt_col, col0, pair_cap)
     S = sim_gemm_banded(st, want_scores)
     rank_resolve(st, S)
     return S, st.count, st

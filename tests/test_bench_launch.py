@@ -1,0 +1,47 @@
+"""bench.py --gpus N without a launcher environment starts N ranks itself (torch.distributed.run as a child process) and relays
+rank 0's single JSON line.  Run here on CPU through LAFF_BENCH_DRYRUN=1: gloo instead of RCCL, the oracle-backed stand-in
+kernels of tests/dist_util.py on a toy problem -- the launch, rendezvous, collective and reporting path of an N > 1 run."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n):
+    env = dict(os.environ, LAFF_BENCH_DRYRUN='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout                     # ONE line on stdout, whatever the ranks printed elsewhere
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks_dryrun():
+    line = _run(2)
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2
+    assert line['steps'] == 2 and line['warmup'] == 1 and line['scaling'] == 'strong'
+    assert line['config']['shard'] == 'video'              # the decomposition BASELINE.json names is the headline
+    assert line['alt_shard']['shard'] == 'text' and line['alt_shard']['ranks_equal']
+    assert line['value'] > 0 and line['ms_per_step'] > 0
+
+
+def test_single_rank_needs_no_launcher_dryrun():
+    line = _run(1)
+    assert line['n_gpus'] == 1 and line['rccl_ranks'] == 1
+
+
+def test_more_gpus_than_the_node_has_is_refused():
+    """Without the dry-run switch the parent counts the visible GPUs before starting anything (0 in this container)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip('this node has the GPUs')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LAFF_BENCH_DRYRUN')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and 'visible GPU' in out.stderr and out.stdout.strip() == ''

@@ -13,76 +13,7 @@ from laff_amd.dist import evaluate_sharded, evaluate_sharded_by_text, shard_boun
 from oracle import laff_oracle as O
 
 
-class Packed:
-    def __init__(self, buf, N, K):
-        self.buf, self.N, self.K, self.precision, self.prescale = buf, N, K, 'fp16', 1.0
-
-
-class OracleBackend:
-    """CPU stand-in with the HipBackend interface: fp16-rounded operands, fp32 GEMM."""
-
-    def __init__(self, Wt, Wv):
-        self.Wt, self.Wv = Wt, Wv
-
-    def embed_text(self, f):
-        return torch.from_numpy(O.l2norm(np.tanh(f['x'].numpy() @ self.Wt)))
-
-    def embed_video(self, f):
-        return torch.from_numpy(O.l2norm(np.tanh(f['x'].numpy() @ self.Wv)))
-
-    def pack(self, E, layer=None):
-        E = E.reshape(E.shape[0], -1)
-        h = E.to(torch.float16).contiguous()
-        return Packed(h.view(torch.uint8).reshape(-1), E.shape[0], E.shape[1])
-
-    def pack_gathered(self, E):
-        return self.pack(E)
-
-    @staticmethod
-    def _mat(p):
-        return p.buf[:p.N * p.K * 2].view(torch.float16).reshape(p.N, p.K).float()
-
-    def sim(self, T, V, heads):
-        return self._mat(T) @ self._mat(V).T
-
-    class State:
-        pass
-
-    def prepare(self, Et, Ev, T, V, gt, col0):
-        """exact ground-truth scores (float64) of the texts whose video is in this shard, -inf elsewhere"""
-        st = self.State()
-        st.Et, st.Ev, st.T, st.V, st.gt, st.col0 = Et, Ev, T, V, gt, col0
-        st.S64 = torch.from_numpy(O.txt2vis_matrix_f64(Et.reshape(Et.shape[0], -1).numpy(), Ev.reshape(Ev.shape[0], -1).numpy()))
-        c = gt.long() - col0
-        ok = (c >= 0) & (c < st.S64.shape[1])
-        st.s_gt64 = torch.full((st.S64.shape[0],), float('-inf'), dtype=torch.float64)
-        st.s_gt64[ok] = st.S64[torch.arange(st.S64.shape[0])[ok], c[ok]]
-        return st
-
-    def s_gt_of(self, st):
-        return st.s_gt64
-
-    def sim_ranked(self, st, want_scores=True):
-        """fp16-operand score block + counts of the EXACT scores above the exact ground-truth score"""
-        S = self.sim(st.T, st.V, 1)
-        cols = torch.arange(S.shape[1])[None, :] + st.col0
-        count = ((st.S64 > st.s_gt64[:, None]) & (cols != st.gt.long()[:, None])).sum(dim=1).to(torch.int32)
-        return S, count
-
-    def metrics(self, ranks):
-        r = ranks.numpy().astype(np.float64)
-        return O.eval_from_positions([[x] for x in r])
-
-
-def _problem(Nt=61, Nv=23, D=32, seed=5):
-    g = np.random.default_rng(seed)
-    zv = g.normal(0, 1, (Nv, 8)).astype(np.float32)
-    gt = (np.arange(Nt) % Nv).astype(np.int32)
-    xv = (zv @ g.normal(0, 1, (8, 16)) + 0.3 * g.normal(0, 1, (Nv, 16))).astype(np.float32)
-    xt = (zv[gt] @ g.normal(0, 1, (8, 16)) + 0.3 * g.normal(0, 1, (Nt, 16))).astype(np.float32)
-    Wt = g.normal(0, 0.3, (16, D)).astype(np.float32)
-    Wv = g.normal(0, 0.3, (16, D)).astype(np.float32)
-    return xt, xv, gt, Wt, Wv
+from dist_util import OracleBackend, problem as _problem  # noqa: E402
 
 
 def _worker(rank, world, port, out_dir):

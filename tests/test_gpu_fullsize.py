@@ -249,8 +249,17 @@ def test_c1_small_whole_path_vs_oracle():
     t2v_ref, v2t_ref = O.predictor_metrics(S, txt_ids, vis_ids)
     t2v, v2t = P.retrieval_metrics(res.S, txt_ids, vis_ids)
     assert np.allclose(t2v, res.metrics, rtol=1e-6)
-    assert np.allclose(t2v, t2v_ref, rtol=1e-3, atol=0.2)       # 1-ulp score flips move at most one query per bucket
-    assert np.allclose(v2t, v2t_ref, rtol=1e-3, atol=3.4)       # 30 videos: one flip = 3.3 pp
+    # the ranking machinery is exact: the oracle's argsort / label loop on the HIP path's OWN scores gives the same 7 + 7 metrics
+    t2v_own, v2t_own = O.predictor_metrics(res.S.cpu().numpy(), txt_ids, vis_ids)
+    assert np.allclose(t2v, t2v_own, rtol=0, atol=1e-9) and np.allclose(v2t, v2t_own, rtol=0, atol=1e-9)
+    # against the oracle's scores (which differ by ~1e-6): a rank may move only where the oracle itself has another video within
+    # 2e-5 of the ground-truth score, and by no more than the number of such videos
+    want = O.count_ranks(S.astype(np.float64), gtn)
+    sg = S[np.arange(Nt), gtn]
+    nn = (np.abs(S - sg[:, None]) < 2e-5).sum(axis=1) - 1
+    got = res.ranks.cpu().numpy()
+    assert np.all(np.abs(got - want) <= nn) and np.array_equal(got[nn == 0], want[nn == 0]) and (nn == 0).mean() > 0.5
+    del t2v_ref, v2t_ref
 
 
 def test_c1_test3k_shapes_sparse_bow_equals_dense_and_oracle_sample():
