@@ -74,6 +74,8 @@ const char* laff_last_error(void) { return g_err.c_str(); }
 int laff_ctx_create(int device, void* hip_stream, laff_ctx** out) {
     if (!out) return fail(LAFF_E_ARG, "laff_ctx_create: null out");
     if (const char* e = getenv("LAFF_GEMM_VARIANT")) laff::g_gemm_variant = atoi(e);
+    if (const char* e = getenv("LAFF_STRIP")) laff::g_strip_mode = atoi(e);
+    if (const char* e = getenv("LAFF_STRIP_MAP")) laff::g_strip_map = atoi(e);
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(LAFF_E_ARG, "laff_ctx_create: device %d out of range (%d devices)", device, n);

@@ -179,7 +179,7 @@ template <int IMM>
 __device__ __forceinline__ void glds_piece_s(unsigned off, unsigned long long sbase, unsigned dst_base) {
     asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                  :: "v"(off), "s"(sbase), "s"(dst_base), "n"(IMM)
-                 : "memory");
+                 : "memory", "scc");          // s_add_i32 writes SCC (a carry chain of the compiler's may be in flight around the asm)
 }
 __device__ __forceinline__ unsigned m0_save() {
     unsigned keep;
@@ -1686,6 +1686,7 @@ hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int stg, hipStream_t s
 }
 
 hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool aligned, hipStream_t st) {
+    if (sim_strip_eligible(a, mode, aligned)) return launch_sim_strip(a, mode, st);     // K = 512 similarity: the strip kernel
     switch (mode) {
         case GEMM_F32: return launch_m<GEMM_F32>(a, aligned, st);
         case GEMM_F16: return launch_m<GEMM_F16>(a, aligned, st);

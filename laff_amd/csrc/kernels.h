@@ -50,6 +50,36 @@ struct GroupedGemmArgs {
     GemmArgs p[MAX_GROUP];
 };
 
+// ---- strip form of the similarity GEMM at K = 512 (sim_strip.hip) ------------------------------------------------------------
+constexpr int STRIP_ROWS = 256;          // text rows per strip (4 wavefronts x 64 rows held in registers)
+constexpr int STRIP_COLS = 32;           // videos per column block (one 32 KiB ring slot)
+constexpr int STRIP_MAX_GROUPS = 2048;   // aligned 64-column groups whose band maxima fit the LDS table (131,072 videos)
+constexpr int STRIP_MAX_WG = 512;        // persistent workgroups (one per CU)
+constexpr int STRIP_ENTRY_WORDS = 24;    // one dumped group: {row, colbase, lo, hi | mask16, gt element (16: none), 0, 0 | 16 raw accumulators}
+struct StripArgs {
+    const void* T;            // [nR][512] 16-bit, rows 1,024 bytes apart
+    const void* V;            // [nC][512]
+    int nR, nC;
+    float* out;               // [nR][ldo] or null
+    int ldo;
+    float scale, inv_scale;
+    const int* gt_col;        // banded count (as GemmArgs); count == null: scores only
+    int col0;
+    const double* s_gt64;
+    const float* band_r;
+    const float* band_c;
+    int* count;
+    unsigned* pairs;          // header {n_overflow, flag, NW | 1 << 31, seg} | NW per-wave counts | entries
+    unsigned pair_cap;
+    int nranges;              // == gridDim.x
+    int debug;                // g_strip_mode (3: K loops only)
+    unsigned long long* trace;   // debug (LAFF_STRIP_TRACE build only): 64 cycle stamps per workgroup
+    unsigned short range_of_wg[STRIP_MAX_WG];
+};
+extern int g_strip_mode, g_strip_map;
+bool sim_strip_eligible(const GemmArgs& a, int mode, bool aligned);
+hipError_t launch_sim_strip(const GemmArgs& a, int mode, hipStream_t st);
+
 hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool aligned, hipStream_t st);
 hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int staging, hipStream_t st);
 hipError_t launch_gemm_nt_grouped_f16(GroupedGemmArgs& g, hipStream_t st);

@@ -356,6 +356,94 @@ hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, 
     return hipGetLastError();
 }
 
+constexpr unsigned RESOLVE_QCAP = 512;           // queued pairs per wavefront (LDS)
+
+// ---- the strip kernel's list: header {n_overflow, overflow flag, NW | 1 << 31, seg} | NW per-wavefront entry counts (rounded up to 4
+// words) | entries of STRIP_ENTRY_WORDS words: NW segments of `seg` entries (the first count[w] of segment w are valid), then
+// n_overflow entries appended with the counter.  An entry = {row, colbase, lo, hi | mask16, gt, 0, 0 | x[16]}: the 16 raw accumulators
+// a lane of the GEMM held for `row` (columns colbase + 8 (e >> 2) + (e & 3)), the accumulator-unit thresholds the GEMM counted
+// against (x > hi was counted there), the elements that may be listed (columns beyond the matrix excluded) and which element, if
+// any (gt < 16), is the row's ground-truth entry: it is never listed, and S takes the exact score there.  A 16-lane group takes an entry, lane e tests element e (lo <= x <= hi: exactly the band test of the tiled kernel's
+// epilogue); the pairs inside the band are queued and re-scored like the pairs of the other list format.
+__device__ __forceinline__ void resolve_groups(const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d,
+                                               const double* __restrict__ s_gt64, int* __restrict__ count, float* __restrict__ S,
+                                               long lds, unsigned* __restrict__ pairs, unsigned pair_cap,
+                                               unsigned (*queue)[RESOLVE_QCAP][2]) {
+    const int sl = threadIdx.x & (RG - 1);
+    const long K = (long)H * d;
+    const unsigned n_over = pairs[0], NW = pairs[2] & 0x7fffffffu, seg = pairs[3];
+    const unsigned cnt_words = (NW + 3u) & ~3u;
+    const unsigned total_words = 2u * pair_cap;
+    const unsigned long long e_total = total_words > cnt_words ? (total_words - cnt_words) / STRIP_ENTRY_WORDS : 0u;
+    const unsigned long long seg_slots = (unsigned long long)NW * seg;
+    const unsigned long long room = e_total > seg_slots ? e_total - seg_slots : 0ull;
+    if (n_over > room) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[1] = 1u; count[0] = -(1 << 26); }
+    }
+    const unsigned long long n_ov = n_over < room ? n_over : room;
+    const unsigned long long slots = seg_slots + n_ov;
+    const unsigned* entries = pairs + 4 + cnt_words;
+    auto one = [&](unsigned r, unsigned c, bool ok) {
+        const double ex = exact_cos(Et + (long)r * K, Ev + (long)c * K, H, d, sl);
+        const double sg = s_gt64[r];
+        const bool above = ex > sg;
+        if (ok && sl == 0) {
+            if (above) atomicAdd(count + r, 1);
+            if (S) {
+                float f = (float)ex;
+                const float sgf = (float)sg;
+                if (above && !(f > sgf)) f = nextafterf(sgf, INFINITY);
+                S[(long)r * lds + c] = f;
+            }
+        }
+    };
+    constexpr unsigned QCAP = RESOLVE_QCAP;
+    const unsigned wv = threadIdx.x >> 6, sub = (threadIdx.x / RG) & 3u;
+    const unsigned group = (blockIdx.x * 256u + threadIdx.x) / RG, ngroups = gridDim.x * (256u / RG);
+    unsigned qn = 0;                                                         // wave-uniform
+    auto drain = [&]() {
+        for (unsigned i = 0; i < qn; i += 4) {
+            const unsigned j = i + sub;
+            const bool ok = j < qn;
+            const unsigned k = ok ? j : qn - 1;
+            one(queue[wv][k][0], queue[wv][k][1], ok);
+        }
+        qn = 0;
+    };
+    const unsigned long long trips = (slots + ngroups - 1) / ngroups;
+    for (unsigned long long it = 0; it < trips; ++it) {                      // wave-uniform trip count
+        if (qn > QCAP - 64) drain();
+        const unsigned long long idx = it * ngroups + group;
+        bool live = idx < slots;
+        if (live && idx < seg_slots) live = (unsigned)(idx % seg) < pairs[4 + (unsigned)(idx / seg)];
+        bool inb = false;
+        unsigned row = 0, col = 0;
+        if (live) {
+            const unsigned* e = entries + idx * STRIP_ENTRY_WORDS;
+            const uint4 h0 = *(const uint4*)e;                               // the 16 lanes of the group read the same 16 bytes
+            const unsigned mask16 = e[4], gt_elem = e[5];
+            const float x = __uint_as_float(e[8 + sl]);
+            const float lo = __uint_as_float(h0.z), hi = __uint_as_float(h0.w);
+            row = h0.x;
+            col = h0.y + 8u * ((unsigned)sl >> 2) + ((unsigned)sl & 3u);
+            if ((unsigned)sl == gt_elem) {
+                // the ground-truth entry of this row: never listed; S takes the exact score there (the GEMM stored its own value)
+                if (S) S[(long)row * lds + col] = (float)s_gt64[row];
+            } else {
+                inb = ((mask16 >> sl) & 1u) && __builtin_amdgcn_fmed3f(x, lo, hi) == x;
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(inb);
+        if (inb) {
+            const unsigned at = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            queue[wv][at][0] = row;
+            queue[wv][at][1] = col;
+        }
+        qn += (unsigned)__builtin_popcountll(m);
+    }
+    drain();
+}
+
 // one 16-lane group per listed pair.  The list (written by the banded GEMM epilogue): header {n_overflow, overflow flag, A, chunk},
 // then A slots in per-wavefront segments of `chunk` slots (valid pairs first, the rest marked row = 0xffffffff), then n_overflow
 // pairs appended with the counter.  A 16-lane group walks a segment until the first invalid slot; the overflow region is shared out
@@ -369,6 +457,12 @@ __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restri
                                                            unsigned pair_cap) {
     const int sl = threadIdx.x & (RG - 1);
     const long K = (long)H * d;
+    constexpr unsigned QCAP = RESOLVE_QCAP;
+    __shared__ unsigned queue[4][QCAP][2];
+    if (pairs[2] & 0x80000000u) {           // the strip kernel's list (sim_strip.hip): dumped groups of 16 raw accumulators
+        resolve_groups(Et, Ev, H, d, s_gt64, count, S, lds, pairs, pair_cap, queue);
+        return;
+    }
     const unsigned n_over = pairs[0], regA = pairs[2];
     const unsigned long long room = pair_cap > regA ? pair_cap - regA : 0u;
     if (n_over > room) {
@@ -394,8 +488,6 @@ __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restri
     //   scan : its four 16-lane groups read blocks of 4 consecutive slots (segments are multiples of 4 slots with their valid pairs
     //          first; the overflow region follows the segments) and queue the valid pairs in LDS (ballot + mbcnt, wave-private);
     //   drain: the queue is re-scored four pairs at a time, one per group.
-    constexpr unsigned QCAP = 512;
-    __shared__ unsigned queue[4][QCAP][2];
     const unsigned wv = threadIdx.x >> 6, sub = (threadIdx.x / RG) & 3u, lane = threadIdx.x & 63u;
     const unsigned n = (unsigned)(n_over < room ? n_over : room);
     const unsigned long long total = (unsigned long long)regA + n;

@@ -499,21 +499,49 @@ class RankState:
         self.Et, self.Ev, self.T, self.V, self.heads, self.gt_col, self.col0 = Et, Ev, T, V, heads, gt_col, col0
         self.s_gt64, self.band_t, self.band_v, self.count, self.pairs, self.pair_cap = s_gt64, band_t, band_v, count, pairs, pair_cap
 
-    def listed_pairs(self):
-        """(number of pairs the GEMM listed, overflow flag) -- synchronises; diagnostics only.  List layout: header {overflow
-        count, overflow flag, A, chunk}, A slots of per-tile segments (unused slots have row 0xffffffff), then the overflow pairs."""
+    GROUP_WORDS = 24      # the strip kernel's list (sim_strip.hip): one dumped group of 16 accumulators per entry
+
+    def _header(self):
         h = self.pairs[:4].cpu().tolist()
-        n_over, flag, reg_a = h[0] & 0xffffffff, h[1], h[2] & 0xffffffff
-        valid = int((self.pairs[4:4 + 2 * reg_a:2] != -1).sum()) if reg_a else 0
-        return valid + n_over, bool(flag)
+        return h[0] & 0xffffffff, h[1], h[2] & 0xffffffff, h[3] & 0xffffffff
+
+    def listed_pairs(self):
+        """(number of pairs inside the error band that the GEMM handed to laff_rank_resolve, overflow flag) -- synchronises;
+        diagnostics only.  Two list layouts (the header's third word tells them apart):
+          tiled kernel: header {overflow count, overflow flag, A, chunk}, A slots of per-wavefront segments (unused slots have row
+                        0xffffffff), then the overflow pairs;
+          strip kernel: header {overflow count, overflow flag, NW | 1 << 31, seg}, NW per-wavefront entry counts, then entries
+                        {row, colbase, lo, hi | mask16, gt element, 0, 0 | 16 raw accumulators}: the pairs are the listed elements
+                        with lo <= x <= hi (the test laff_rank_resolve applies)."""
+        return int(self.pair_indices().shape[0]), bool(self._header()[1])
 
     def pair_indices(self):
-        """(n, 2) int64 tensor of the listed (row, col) pairs -- synchronises; diagnostics / tests only."""
-        h = self.pairs[:4].cpu().tolist()
-        n_over, reg_a = h[0] & 0xffffffff, h[2] & 0xffffffff
-        seg = self.pairs[4:4 + 2 * reg_a].view(-1, 2)
-        over = self.pairs[4 + 2 * reg_a:4 + 2 * (reg_a + min(n_over, self.pair_cap - reg_a))].view(-1, 2)
-        return torch.cat([seg[seg[:, 0] != -1], over]).long()
+        """(n, 2) int64 tensor of the (row, col) pairs inside the band -- synchronises; diagnostics / tests only."""
+        n_over, _, third, fourth = self._header()
+        if not (third & 0x80000000):
+            reg_a = third
+            seg = self.pairs[4:4 + 2 * reg_a].view(-1, 2)
+            over = self.pairs[4 + 2 * reg_a:4 + 2 * (reg_a + min(n_over, max(self.pair_cap - reg_a, 0)))].view(-1, 2)
+            return torch.cat([seg[seg[:, 0] != -1], over]).long()
+        nw, seg, W = third & 0x7fffffff, fourth, self.GROUP_WORDS
+        cnt_words = (nw + 3) & ~3
+        e_total = max(2 * self.pair_cap - cnt_words, 0) // W
+        counts = self.pairs[4:4 + nw].long().clamp(max=seg)
+        ent = self.pairs[4 + cnt_words:4 + cnt_words + e_total * W].view(-1, W)
+        live = torch.zeros(e_total, dtype=torch.bool, device=ent.device)
+        if nw * seg:
+            live[:nw * seg] = (torch.arange(seg, device=ent.device)[None, :] < counts[:, None]).reshape(-1)
+        live[nw * seg:nw * seg + min(n_over, max(e_total - nw * seg, 0))] = True
+        ent = ent[live]
+        if ent.shape[0] == 0:
+            return torch.zeros((0, 2), dtype=torch.int64, device=ent.device)
+        e = torch.arange(16, device=ent.device)
+        x = ent[:, 8:24].view(torch.float32)
+        lo, hi = ent[:, 2:3].view(torch.float32), ent[:, 3:4].view(torch.float32)
+        listed = ((ent[:, 4:5] >> e[None, :]) & 1).bool() & (e[None, :] != ent[:, 5:6]) & (x >= lo) & (x <= hi)
+        rows = ent[:, 0:1].long().expand(-1, 16)
+        cols = ent[:, 1:2].long() + 8 * (e >> 2)[None, :] + (e & 3)[None, :]
+        return torch.stack([rows[listed], cols[listed]], dim=1)
 
 
 def _emb3(E, name):
