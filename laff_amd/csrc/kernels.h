@@ -55,7 +55,8 @@ constexpr int STRIP_ROWS = 256;          // text rows per strip (4 wavefronts x 
 constexpr int STRIP_COLS = 32;           // videos per column block (one 32 KiB ring slot)
 constexpr int STRIP_MAX_GROUPS = 2048;   // aligned 64-column groups whose band maxima fit the LDS table (131,072 videos)
 constexpr int STRIP_MAX_WG = 512;        // persistent workgroups (one per CU)
-constexpr int STRIP_ENTRY_WORDS = 24;    // one dumped group: {row, colbase, lo, hi | mask16, gt element (16: none), 0, 0 | 16 raw accumulators}
+constexpr int STRIP_CHUNK = 64;          // entries per chunk of the dump list (a wavefront takes a new chunk with one atomic)
+constexpr int STRIP_ENTRY_WORDS = 24;    // one dumped group: {row, colbase, lo, hi | mask16, the row's ground-truth column, 0, 0 | 16 raw accumulators}
 struct StripArgs {
     const void* T;            // [nR][512] 16-bit, rows 1,024 bytes apart
     const void* V;            // [nC][512]
@@ -69,7 +70,7 @@ struct StripArgs {
     const float* band_r;
     const float* band_c;
     int* count;
-    unsigned* pairs;          // header {n_overflow, flag, NW | 1 << 31, seg} | NW per-wave counts | entries
+    unsigned* pairs;          // header {chunks taken, flag, NW | 1 << 31, NCH} | NCH per-chunk counts | NCH chunks of STRIP_CHUNK entries
     unsigned pair_cap;
     int nranges;              // == gridDim.x
     int debug;                // g_strip_mode (3: K loops only)

@@ -358,31 +358,29 @@ hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, 
 
 constexpr unsigned RESOLVE_QCAP = 512;           // queued pairs per wavefront (LDS)
 
-// ---- the strip kernel's list: header {n_overflow, overflow flag, NW | 1 << 31, seg} | NW per-wavefront entry counts (rounded up to 4
-// words) | entries of STRIP_ENTRY_WORDS words: NW segments of `seg` entries (the first count[w] of segment w are valid), then
-// n_overflow entries appended with the counter.  An entry = {row, colbase, lo, hi | mask16, gt, 0, 0 | x[16]}: the 16 raw accumulators
-// a lane of the GEMM held for `row` (columns colbase + 8 (e >> 2) + (e & 3)), the accumulator-unit thresholds the GEMM counted
-// against (x > hi was counted there), the elements that may be listed (columns beyond the matrix excluded) and which element, if
-// any (gt < 16), is the row's ground-truth entry: it is never listed, and S takes the exact score there.  A 16-lane group takes an entry, lane e tests element e (lo <= x <= hi: exactly the band test of the tiled kernel's
-// epilogue); the pairs inside the band are queued and re-scored like the pairs of the other list format.
+// ---- the strip kernel's list (sim_strip.hip): header {chunks taken from the pool, overflow flag, NW | 1 << 31, NCH} | NCH per-chunk
+// entry counts (rounded up to 4 words) | NCH chunks of STRIP_CHUNK entries of STRIP_ENTRY_WORDS words.  Chunks 0 .. NW - 1 belong to
+// the GEMM's wavefronts, chunks NW .. NW + taken - 1 were taken from the pool; the first count[c] entries of chunk c are valid.
+// An entry = {row, colbase, lo, hi | mask16, gt, 0, 0 | x[16]}: the 16 raw accumulators a lane of the GEMM held for `row` (columns
+// colbase + 8 (e >> 2) + (e & 3)), the accumulator-unit thresholds the GEMM counted against (x > hi was counted there), the elements
+// that may be listed (columns beyond the matrix excluded) and the row's ground-truth column (shard-local): that element is never
+// listed, and S takes the exact score there.  A 16-lane group takes an entry, lane e tests element e (lo <= x <= hi: exactly the band
+// test of the tiled kernel's epilogue); the pairs inside the band are queued and re-scored like the pairs of the other list format.
 __device__ __forceinline__ void resolve_groups(const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d,
                                                const double* __restrict__ s_gt64, int* __restrict__ count, float* __restrict__ S,
                                                long lds, unsigned* __restrict__ pairs, unsigned pair_cap,
                                                unsigned (*queue)[RESOLVE_QCAP][2]) {
     const int sl = threadIdx.x & (RG - 1);
     const long K = (long)H * d;
-    const unsigned n_over = pairs[0], NW = pairs[2] & 0x7fffffffu, seg = pairs[3];
-    const unsigned cnt_words = (NW + 3u) & ~3u;
-    const unsigned total_words = 2u * pair_cap;
-    const unsigned long long e_total = total_words > cnt_words ? (total_words - cnt_words) / STRIP_ENTRY_WORDS : 0u;
-    const unsigned long long seg_slots = (unsigned long long)NW * seg;
-    const unsigned long long room = e_total > seg_slots ? e_total - seg_slots : 0ull;
-    if (n_over > room) {
+    const unsigned taken = pairs[0], NW = pairs[2] & 0x7fffffffu, NCH = pairs[3];
+    const unsigned cnt_words = (NCH + 3u) & ~3u;
+    if (pairs[1] != 0u || NW > NCH || taken > NCH - (NW < NCH ? NW : NCH)) {            // the pool ran out: entries were dropped
         if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[1] = 1u; count[0] = -(1 << 26); }
     }
-    const unsigned long long n_ov = n_over < room ? n_over : room;
-    const unsigned long long slots = seg_slots + n_ov;
+    const unsigned long long nchunks = (unsigned long long)NW + taken < NCH ? (unsigned long long)NW + taken : NCH;
+    const unsigned long long slots = nchunks * STRIP_CHUNK;
     const unsigned* entries = pairs + 4 + cnt_words;
+    (void)pair_cap;
     auto one = [&](unsigned r, unsigned c, bool ok) {
         const double ex = exact_cos(Et + (long)r * K, Ev + (long)c * K, H, d, sl);
         const double sg = s_gt64[r];
@@ -414,19 +412,18 @@ __device__ __forceinline__ void resolve_groups(const float* __restrict__ Et, con
     for (unsigned long long it = 0; it < trips; ++it) {                      // wave-uniform trip count
         if (qn > QCAP - 64) drain();
         const unsigned long long idx = it * ngroups + group;
-        bool live = idx < slots;
-        if (live && idx < seg_slots) live = (unsigned)(idx % seg) < pairs[4 + (unsigned)(idx / seg)];
+        const bool live = idx < slots && (unsigned)(idx % STRIP_CHUNK) < pairs[4 + (unsigned)(idx / STRIP_CHUNK)];
         bool inb = false;
         unsigned row = 0, col = 0;
         if (live) {
             const unsigned* e = entries + idx * STRIP_ENTRY_WORDS;
             const uint4 h0 = *(const uint4*)e;                               // the 16 lanes of the group read the same 16 bytes
-            const unsigned mask16 = e[4], gt_elem = e[5];
+            const unsigned mask16 = e[4], gt_col = e[5];
             const float x = __uint_as_float(e[8 + sl]);
             const float lo = __uint_as_float(h0.z), hi = __uint_as_float(h0.w);
             row = h0.x;
             col = h0.y + 8u * ((unsigned)sl >> 2) + ((unsigned)sl & 3u);
-            if ((unsigned)sl == gt_elem) {
+            if (col == gt_col) {
                 // the ground-truth entry of this row: never listed; S takes the exact score there (the GEMM stored its own value)
                 if (S) S[(long)row * lds + col] = (float)s_gt64[row];
             } else {

@@ -56,10 +56,9 @@ constexpr int KBYTES = 1024;                   // K = 512 16-bit elements
 constexpr int STAGE = CB * KBYTES;             // one ring slot: 32 KiB
 constexpr int RING = 3;                        // ring slots: block b lives in slot b % 3
 constexpr int PIECES = CB / 4;                 // 1 KiB LDS-DMA pieces (= columns) per wave per block
-constexpr int SLAB_OFF = RING * STAGE;         // per-wave 32 x 32 fp32 transpose slab as two halves of 16 columns
-constexpr int SLAB_PITCH = 20;                 // words per row of one 32 x 16 half
-constexpr int SLAB_HALF = 32 * SLAB_PITCH * 4;
-constexpr int SLAB_BYTES = 2 * SLAB_HALF;
+constexpr int SLAB_OFF = RING * STAGE;         // per-wave fp32 transpose slabs, one per job (32 rows x 32 columns) of a column block:
+constexpr int SLAB_JOB = 32 * 128;             // 128-byte rows, 16-byte chunk c of row r at position c ^ ((r >> 1) & 3) -- conflict-free for
+constexpr int SLAB_BYTES = 2 * SLAB_JOB;       // the quad-column ds_write_b128 (8 rows at a time) and the row-wise ds_read_b128 (a row per 8 lanes)
 constexpr int BAND_OFF = SLAB_OFF + 4 * SLAB_BYTES;       // band maximum of every aligned group of 64 columns (fp32)
 constexpr int SMEM = BAND_OFF + STRIP_MAX_GROUPS * 4;
 static_assert(SMEM <= 160 * 1024 && CB == 32, "LDS budget / block width");
@@ -179,17 +178,17 @@ constexpr int slot_dma_piece(int sg) {       // DMA piece issued in this slot: 0
 constexpr int BAND_READ_SLOT = 2 * (31 - FDIST);       // the slot of this block's last fragment read
 
 // The epilogue of a column block as a static stream of micro-ops.  Job = row block rb (32 x 32 accumulators).  Per accumulator e:
-//   MUL  v[e & 3] = x * scale                      (scores wanted)
 //   SUBALN  t = hi - x ; sh = (sh << 1) | sign(t) ; MIN (odd e)  m = umin(m, bits(t_prev), bits(t))            (banded count)
-//   DSW  after every 4th: ds_write_b128 of v[0..3] into the wave's slab (half A: quads 0, 1; half B: quads 2, 3)
-// then CHK (any 0 <= t <= w in the job?  -> dump, rare), CNT (count += popcount of the 16 sign bits), DSR i (slab rows back: read
-// i = 2 half + r covers rows 16 r .. 16 r + 15 of that 16-column half, 64 bytes per row, into one of 2 x 4 registers), WAITR half,
-// then STG per read (address add + non-temporal 16-byte buffer store, 16 rows x 64 bytes per instruction).  Half B of job 0 is stored from
-// job 1's element stream and half B of job 1 at the end, so that the LDS latency of the read-back is covered.
+//   DSW  after every 4th: the quad times scale, ds_write_b128 into the job's slab                                 (scores wanted)
+// then CHK (any 0 <= t <= w in the job?  -> dump, rare), CNT (count += popcount of the 16 sign bits), DSR i (slab rows 8 i .. 8 i + 7
+// back, 128 bytes per row, into 4 registers of its own), and per read WAITR + STG (non-temporal 16-byte buffer store, 8 rows x 128
+// bytes per instruction).  Job 0 is stored from job 1's element stream and job 1 at the end, so that the LDS latency of the
+// read-back is covered and the stores are spread over the block.
 enum : unsigned char { OP_MUL = 0, OP_SUBALN, OP_MIN, OP_DSW, OP_CHK, OP_CNT, OP_DSR, OP_WAITR, OP_STG, OP_GAP };
-constexpr int op_cost(unsigned char k) { return k == OP_STG ? 3 : (k == OP_SUBALN ? 2 : 1); }       // instructions of one stream item
+constexpr int op_cost(unsigned char k) { return k == OP_DSW ? 5 : (k == OP_SUBALN ? 2 : 1); }      // (DSW: 4 products + the LDS store unless scale == 1)       // instructions of one stream item
 struct EpiOp { unsigned char kind, job, arg; };
 constexpr int EPI_MAX_OPS = 256;
+constexpr int TAIL_GAP = 3;
 struct EpiStream { EpiOp op[EPI_MAX_OPS]; int n; };
 
 template <bool HAVE_S, bool BANDED>
@@ -199,35 +198,34 @@ constexpr EpiStream make_epi_stream() {
     auto push = [&](unsigned char k, int job, int arg) { s.op[s.n++] = EpiOp{k, (unsigned char)job, (unsigned char)arg}; };
     for (int job = 0; job < 2; ++job) {
         for (int e = 0; e < 16; ++e) {
-            if (HAVE_S) push(OP_MUL, job, e);
             if (BANDED) {
                 push(OP_SUBALN, job, e);
                 if (e >= 3 && (e & 1)) push(OP_MIN, job, e - 2);         // the pair (e - 3, e - 2): two statements behind its second SUBALN
             }
             if (HAVE_S) {
                 if ((e & 3) == 3) push(OP_DSW, job, e >> 2);
-                if (job > 0 && e == 4) push(OP_WAITR, job - 1, 1);
-                if (job > 0 && (e == 4 || e == 5)) push(OP_STG, job - 1, 2 + (e - 4));
-                if (e == 8 || e == 9) push(OP_DSR, job, e - 8);
-                if (e == 13) push(OP_WAITR, job, 0);
-                if (e == 13 || e == 14) push(OP_STG, job, e - 13);
+                // Job 0's four stores ride in job 1's element stream, one every fourth element: a store instruction is 8 rows x 128
+                // bytes, whole cache lines where the row pitch allows (as 16 rows x 64 bytes the same bytes left the chip at 3.2 TB/s,
+                // this way at 4.0: scratch/probe/stprobe), and a row of the slab is complete only behind the job's last quad.
+                if (job > 0 && (e & 3) == 3) { push(OP_WAITR, 0, e >> 2); push(OP_STG, 0, e >> 2); }
             }
         }
         if (BANDED) { push(OP_MIN, job, 15); push(OP_CHK, job, 0); push(OP_CNT, job, 0); }
-        if (HAVE_S) for (int i = 2; i < 4; ++i) push(OP_DSR, job, i);
+        if (HAVE_S) for (int i = 0; i < 4; ++i) push(OP_DSR, job, i);
     }
-    if (HAVE_S) {
-        for (int g = 0; g < 3; ++g) push(OP_GAP, 1, 0);
-        push(OP_WAITR, 1, 1);
-        for (int i = 2; i < 4; ++i) push(OP_STG, 1, i);
-    }
+    if (HAVE_S)
+        for (int i = 0; i < 4; ++i) {
+            // job 1's stores: the tail of the stream, TAIL_GAP slots apart
+            if (i) for (int g = 0; g < TAIL_GAP; ++g) push(OP_GAP, 1, 0);
+            push(OP_WAITR, 1, i); push(OP_STG, 1, i);
+        }
     return s;
 }
 
 struct EpiPlan {
     short begin[NSLOT + 1];    // stream range of slot sigma: [begin[sigma], begin[sigma + 1])
     short wait_frag[32];       // lgkmcnt operand in front of sub-step J: LDS operations issued after the fragment read of J
-    short wait_r[2][2];        // ... in front of the stores of (job, half): LDS operations issued after that half's last slab read
+    short wait_r[2][4];        // ... in front of the store of (job, read i): LDS operations issued after that slab read
     short lgkm_bar, vm_bar;    // operands of the block barrier's waits
     bool fits;
 };
@@ -252,7 +250,7 @@ constexpr EpiPlan make_epi_plan() {
         p.begin[sg] = (short)at;
         if ((sg >> 1) >= BAR_J || slot_dma_piece(sg) >= 0) continue;   // the thresholds change at the barrier; DMA slots are full
         ++k;
-        const int spread = usable - 6;                                // the gap items of the tail each cost a slot
+        const int spread = usable - (HAVE_S ? 3 * TAIL_GAP + 4 : 2);  // the gap items of the tail each cost a slot
         const int target = (int)(((long)k * total_cost + spread - 1) / spread);
         while (at < st.n && spent < target) {
             spent += op_cost(st.op[at].kind);
@@ -267,7 +265,7 @@ constexpr EpiPlan make_epi_plan() {
     int frag_ord[2][40] = {};           // [body][sub-step index as returned by slot_read_sub]: LDS ordinal of that read
     int band_ord[2] = {0, 0};
     int lds_before[2 * NSLOT + 1] = {}, vm_before[2 * NSLOT + 1] = {};
-    int dsr_ord[2][2] = {}, waitr_at[2][2] = {};
+    int dsr_ord[2][4] = {}, waitr_at[2][4] = {};
     int last_early_vm[2] = {0, 0};
     for (int body = 0; body < 2; ++body)
         for (int sg = 0; sg < NSLOT; ++sg) {
@@ -286,16 +284,18 @@ constexpr EpiPlan make_epi_plan() {
                 if (o.kind == OP_DSW || o.kind == OP_DSR) ++lds_n;
                 if (o.kind == OP_STG) ++vm_n;
                 if (body == 1) {
-                    if (o.kind == OP_DSR && (o.arg & 1)) dsr_ord[o.job][o.arg >> 1] = lds_n;
+                    if (o.kind == OP_DSR) dsr_ord[o.job][o.arg] = lds_n;
                     if (o.kind == OP_WAITR) waitr_at[o.job][o.arg] = lds_n;
                 }
             }
         }
     auto clamp = [](int c, int hi) { return c < 0 ? 0 : (c > hi ? hi : c); };
     for (int J = 0; J < 32; ++J) {
-        // sub-step J's fragment: asked for in this body (J >= FDIST) or as "next block" sub-step 32 + J in the previous one
-        const int ord = J >= FDIST ? frag_ord[1][J] : frag_ord[0][32 + J];
-        p.wait_frag[J] = (short)clamp(lds_before[NSLOT + 2 * J] - ord, 15);
+        // one wait per PAIR of sub-steps, in front of the even one, for the odd one's fragment (asked for later: it covers both).
+        // That fragment: asked for in this body (>= FDIST) or as "next block" sub-step 32 + j in the previous one
+        const int Jn = J | 1;
+        const int ord = Jn >= FDIST ? frag_ord[1][Jn] : frag_ord[0][32 + Jn];
+        p.wait_frag[J] = (short)clamp(lds_before[NSLOT + 2 * (J & ~1)] - ord, 15);
     }
     {
         // the barrier: this block's last fragment read (and the band value right behind it) ...
@@ -305,16 +305,16 @@ constexpr EpiPlan make_epi_plan() {
         p.vm_bar = (short)clamp(vm_before[NSLOT + 2 * BAR_J] - last_early_vm[0], 63);
     }
     for (int k = 0; k < 2; ++k)
-        for (int h = 0; h < 2; ++h) p.wait_r[k][h] = (short)clamp(waitr_at[k][h] - dsr_ord[k][h], 15);
+        for (int h = 0; h < 4; ++h) p.wait_r[k][h] = (short)clamp(waitr_at[k][h] - dsr_ord[k][h], 15);
     return p;
 }
 
 }  // namespace
 
-// MODE: GEMM_F16 / GEMM_BF16.  BANDED: exact-rank count + dumps.  HAVE_S: the fp32 score matrix is written.
+// MODE: GEMM_F16 / GEMM_BF16.  BANDED: exact-rank count + dumps.  HAVE_S: the fp32 score matrix is written (SCALE1: scale == 1).
 // Debug builds: -DLAFF_STRIP_SERIAL = the K loops alone, no epilogue (timing only, no output), -DLAFF_STRIP_TRACE = cycle stamps,
 // -DLAFF_STRIP_ABL = ablations of the K loop.
-template <int MODE, bool BANDED, bool HAVE_S>
+template <int MODE, bool BANDED, bool HAVE_S, bool SCALE1>
 __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -346,22 +346,24 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
     long u0 = U * myrange / nranges;
     const long u1 = U * (myrange + 1) / nranges;
 
-    // the dump list: header (4 words) | per-wave entry counts (NW words, rounded up to 4) | entries of STRIP_ENTRY_WORDS words
+    // the dump list: header {chunks taken from the pool, overflow flag, NW | 1 << 31, NCH} | NCH per-chunk entry counts | NCH chunks of
+    // STRIP_CHUNK entries of STRIP_ENTRY_WORDS words.  Wavefront w starts in chunk w; a full chunk is closed (its count written) and
+    // the next one taken from the pool with ONE atomic per STRIP_CHUNK entries (the atomic's return drains this wave's memory queue:
+    // per entry, as a first version had it behind small fixed segments, it cost a third of the launch).
     const unsigned NW = (unsigned)nranges * 4u;
-    const unsigned cnt_words = (NW + 3u) & ~3u;
     const unsigned total_words = 2u * pin_s(a.pair_cap);
-    const unsigned e_total = total_words > cnt_words ? (total_words - cnt_words) / STRIP_ENTRY_WORDS : 0u;
-    const unsigned seg = pin_s((e_total / 2u) / (NW ? NW : 1u));            // entries of one wave's own segment; the rest: overflow
+    const unsigned NCH = pin_s(total_words / (1u + STRIP_CHUNK * STRIP_ENTRY_WORDS));
+    const unsigned cnt_words = (NCH + 3u) & ~3u;
     const unsigned wave_global = (unsigned)blockIdx.x * 4u + (unsigned)wave;
-    unsigned wcount = 0;                                                    // wave-uniform: groups dumped by this wave so far
-    const unsigned list_base = pin_s((4u + cnt_words) * 4u);                // byte offset of entry 0 in the list
+    unsigned cur_chunk = wave_global, cur_n = 0;                            // wave-uniform: the chunk being filled, entries in it
+    const unsigned list_base = pin_s((4u + cnt_words) * 4u);                // byte offset of chunk 0 in the list
     u32x4 rsrcP = {0, 0, 0, 0x00020000u};                                   // the whole list as a raw buffer
     if constexpr (BANDED) {
         rsrcP = rebased_rsrc(pPairs, 16ull + 8ull * a.pair_cap, 0ull);
         if (blockIdx.x == 0 && tid == 0) {
             gu32* pp = (gu32*)pPairs;
             pp[2] = NW | 0x80000000u;
-            pp[3] = seg;
+            pp[3] = NCH;
         }
         // band maxima of the aligned 64-column groups -> LDS (laff_rank_prepare stores them behind the per-column values)
         const float* bm = a.band_c + ((nC + 3) & ~3);
@@ -381,8 +383,13 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
     const unsigned m0_keep = m0_get();
     // slab addresses of this wave: written in accumulator layout (row l31, 4 consecutive columns per quad), read back as rows
     const unsigned slab0 = lds0 + SLAB_OFF + (unsigned)wave * SLAB_BYTES;
-    const unsigned slab_w = slab0 + (unsigned)(l31 * SLAB_PITCH + 4 * hh) * 4u;
-    const unsigned slab_r = slab0 + (unsigned)((lane >> 2) * SLAB_PITCH + (lane & 3) * 4) * 4u;
+    // lane (l31, hh) holds of text row l31 the column quads 2 q + hh (q = e >> 2): chunk position (2 q + hh) ^ k, k = (l31 >> 1) & 3
+    // = (q >> 1) * 64 bytes + [q & 1]
+    const unsigned slab_k = (unsigned)(l31 >> 1) & 3u;
+    const unsigned slab_w0 = slab0 + (unsigned)l31 * 128u + ((((slab_k >> 1) << 1) | ((unsigned)hh ^ (slab_k & 1u))) << 4);     // q & 1 == 0
+    const unsigned slab_w1 = slab_w0 ^ 32u;                                                                                  // q & 1 == 1
+    // read-back i: rows 8 i .. 8 i + 7, a whole 128-byte row per 8 lanes ((r >> 1) & 3 of row 8 i + (lane >> 3) is (lane >> 4) & 3)
+    const unsigned slab_r = slab0 + (unsigned)(lane >> 3) * 128u + (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4);
     const unsigned wrow = (unsigned)(PIECES * wave) * KBYTES;              // this wave's 8 columns of a block (LDS and source offset)
 
 #ifndef LAFF_STRIP_SERIAL
@@ -441,18 +448,17 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
         // epilogue state
         unsigned sh[4] = {0, 0, 0, 0}, mm = 0;
         float tt[4] = {0, 0, 0, 0};
-        float vs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        u32x4 rr[2];
-        unsigned sa[2] = {0, 0};
+        u32x4 rr[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         u32x4 rsrcSb = {0, 0, 0, 0x00020000u};      // the score rows of the block whose epilogue is running
         // score rows of this strip as a raw buffer (re-based per column block): rows beyond the matrix are dropped by its bounds check
         unsigned long long s_base = 0ull, s_bytes = 0ull;
-        unsigned voff_base = 0, ld16 = 0;             // a store instruction covers 16 rows x 64 bytes; ld16 = bytes between 16-row groups
+        unsigned voffs[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // a store instruction covers 8 rows x 128 bytes (whole lines where the row pitch allows): the wave's 8 row groups
         if constexpr (HAVE_S) {
             s_base = pOut + (unsigned long long)row0 * (unsigned)ldo * 4ull;
             s_bytes = ((unsigned long long)(std::min(SR, nR - row0) - 1) * (unsigned)ldo + (unsigned)nC) * 4ull;
-            voff_base = ((unsigned)(wave * 64 + (lane >> 2)) * (unsigned)ldo + (unsigned)(lane & 3) * 4u) * 4u;
-            ld16 = __builtin_amdgcn_readfirstlane(16u * (unsigned)ldo * 4u);
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8)
+                voffs[k8] = ((unsigned)(wave * 64 + 8 * k8 + (lane >> 3)) * (unsigned)ldo + (unsigned)(lane & 7) * 4u) * 4u;
         }
         // running descriptors of the block loop: the score columns of block b - 1 (sb_*: base of block cb0 - 1 first, bytes left from
         // block cb0 on) and the video rows of block b + 2 (rsrcNext)
@@ -486,33 +492,40 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
             lds_read128<(j >> 3) * 256>(fr[j & 7], X[j & 7]);
         });
 
-        // ---- one dumped group: 16 raw accumulators of one lane + what laff_rank_resolve needs to test them.  Six 16-byte buffer stores
-        // straight from the accumulator registers (32-bit offsets into the list, the descriptor's bounds check drops what does not
-        // fit): a pointer-based version of this -- inlined several times -- cost the kernel 90 spilled registers.
-        auto dump_group = [&](bool hit, int row, int colbase, float lo, float hi, unsigned mask16, unsigned gt_elem, const f32x16& x) {
+        // ---- one dumped group: 16 raw accumulators of one lane + what laff_rank_resolve needs to test them {row, colbase, lo, hi |
+        // mask16, the row's ground-truth column, 0, 0 | x[16]}.  Six 16-byte buffer stores, four of them straight from the accumulator
+        // registers (32-bit offsets into the list; the descriptor's bounds check drops what does not fit).
+        auto dump_group = [&](bool hit, int row, int colbase, float lo, float hi, unsigned mask16, int gt_col_of_row, const f32x16& x) {
             const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
             if (m == 0ull) return;
-            const unsigned slot = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            wcount = __builtin_amdgcn_readfirstlane(wcount + (unsigned)__builtin_popcountll(m));
+            const unsigned n = (unsigned)__builtin_popcountll(m);
+            if (cur_n + n > STRIP_CHUNK) {                                   // wave-uniform, once per STRIP_CHUNK entries at most
+                gu32* pp = (gu32*)pPairs;
+                if (lane == 0 && cur_chunk < NCH) pp[4 + cur_chunk] = cur_n;  // close the chunk
+                unsigned nc = 0;
+                if (lane == 0) nc = NW + __hip_atomic_fetch_add(pp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cur_chunk = __builtin_amdgcn_readfirstlane(nc);
+                cur_n = 0;
+                if (lane == 0 && cur_chunk >= NCH) pp[1] = 1u;                // pool exhausted: flagged, the entries are dropped
+            }
+            const unsigned slot = cur_n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            const unsigned cbase = cur_chunk < NCH ? list_base + cur_chunk * (STRIP_CHUNK * STRIP_ENTRY_WORDS * 4u) : 0x80000000u;
+            cur_n += n;
             if (hit) {
-                unsigned idx = wave_global * seg + slot;
-                if (slot >= seg)         // this wave's segment is full: the shared overflow region behind the segments (pairs[0] counts it)
-                    idx = NW * seg + __hip_atomic_fetch_add((gu32*)pPairs, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned voff = idx < e_total ? list_base + idx * (STRIP_ENTRY_WORDS * 4u) : 0xfffffff0u;     // beyond the list: dropped
-                u32x4 h;
-                h.x = (unsigned)row; h.y = (unsigned)colbase; h.z = __float_as_uint(lo); h.w = __float_as_uint(hi);
-                // (s_nop behind every store: hipcc does not know these are stores, and a 16-byte store reads its data registers for a
-                // few cycles after issue -- the next instruction may be a write to them)
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 3" ::"v"(h), "v"(voff), "s"(rsrcP) : "memory");
-                u32x4 h2;
-                h2.x = mask16; h2.y = gt_elem; h2.z = 0u; h2.w = 0u;
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:16\n\ts_nop 3" ::"v"(h2), "v"(voff), "s"(rsrcP) : "memory");
+                const unsigned voff = cbase + slot * (STRIP_ENTRY_WORDS * 4u);
                 const f32x4 q0 = {x[0], x[1], x[2], x[3]}, q1 = {x[4], x[5], x[6], x[7]}, q2 = {x[8], x[9], x[10], x[11]},
                             q3 = {x[12], x[13], x[14], x[15]};
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:32\n\ts_nop 3" ::"v"(q0), "v"(voff), "s"(rsrcP) : "memory");
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:48\n\ts_nop 3" ::"v"(q1), "v"(voff), "s"(rsrcP) : "memory");
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:64\n\ts_nop 3" ::"v"(q2), "v"(voff), "s"(rsrcP) : "memory");
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:80\n\ts_nop 3" ::"v"(q3), "v"(voff), "s"(rsrcP) : "memory");
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:32" ::"v"(q0), "v"(voff), "s"(rsrcP) : "memory");
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:48" ::"v"(q1), "v"(voff), "s"(rsrcP) : "memory");
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:64" ::"v"(q2), "v"(voff), "s"(rsrcP) : "memory");
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:80" ::"v"(q3), "v"(voff), "s"(rsrcP) : "memory");
+                u32x4 h, h2;
+                h.x = (unsigned)row; h.y = (unsigned)colbase; h.z = __float_as_uint(lo); h.w = __float_as_uint(hi);
+                h2.x = mask16; h2.y = (unsigned)gt_col_of_row; h2.z = 0u; h2.w = 0u;
+                // (s_nop behind the header stores: hipcc does not know these are stores, and a 16-byte store reads its data registers
+                // for a few cycles after issue -- the temporaries may be handed to the very next instruction)
+                asm volatile("buffer_store_dwordx4 %0, %1, %3, 0 offen\n\tbuffer_store_dwordx4 %2, %1, %3, 0 offen offset:16\n\ts_nop 1"
+                             ::"v"(h), "v"(voff), "v"(h2), "s"(rsrcP) : "memory");
             }
         };
 
@@ -562,17 +575,18 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                     x[4 * q + 2] = __uint_as_float(t.z); x[4 * q + 3] = __uint_as_float(t.w);
                 }
                 if constexpr (BANDED) {
-                    unsigned mask16 = 0u, gi = 16u;
+                    unsigned mask16 = 0u;
+                    bool has_gt = false;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int col = colbase + 8 * (e >> 2) + (e & 3);
                         const bool valid = rv && col < nC && col != gt;
-                        if (rv && col == gt) gi = (unsigned)e;
+                        has_gt |= rv && col == gt;
                         c_here += (valid && x[e] > hi) ? 1 : 0;
                         const bool inb = valid && __builtin_amdgcn_fmed3f(x[e], lo, hi) == x[e];
                         mask16 |= inb ? (1u << e) : 0u;
                     }
-                    dump_group(mask16 != 0u || gi < 16u, row, colbase, lo, hi, mask16, gi, x);
+                    dump_group(mask16 != 0u || has_gt, row, colbase, lo, hi, mask16, gt, x);
                 }
                 if (HAVE_S && rv) {
                     gf32* orow = (gf32*)pOut + (size_t)row * ldo;
@@ -605,50 +619,81 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
             // The per-element operations are inline asm: as plain expressions they are pure values to hipcc, which sank them all next to
             // their uses (two slots of 66 and 109 instructions per block, the rest empty) whatever sched_barrier said.
             if constexpr (op.kind == OP_MUL) {
-                // (two register quads in turn: the LDS store of a quad is still reading its data registers when the next quad's first
-                // product is issued right behind it -- nothing interlocks an asm store's sources against an asm VALU write)
-                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(vs[arg & 7]) : "s"(scale), "v"(acc[Q][rb][arg]));
             } else if constexpr (op.kind == OP_SUBALN) {
                 // (one asm statement per dependent pair: between two statements hipcc puts an s_nop for the register they share)
-                asm volatile("v_sub_f32 %0, %2, %3\n\tv_alignbit_b32 %1, %1, %0, 31"
-                             : "=&v"(tt[arg & 3]), "+v"(sh[arg & 3]) : "v"(thr_hi[rb]), "v"(acc[Q][rb][arg]));
+                // (the first four elements of a job start their shift register afresh: four sign bits per register, nothing to mask)
+                if constexpr (arg < 4)
+                    asm volatile("v_sub_f32 %0, %2, %3\n\tv_lshrrev_b32 %1, 31, %0"
+                                 : "=&v"(tt[arg & 3]), "=v"(sh[arg & 3]) : "v"(thr_hi[rb]), "v"(acc[Q][rb][arg]));
+                else
+                    asm volatile("v_sub_f32 %0, %2, %3\n\tv_alignbit_b32 %1, %1, %0, 31"
+                                 : "=&v"(tt[arg & 3]), "+v"(sh[arg & 3]) : "v"(thr_hi[rb]), "v"(acc[Q][rb][arg]));
             } else if constexpr (op.kind == OP_MIN) {
                 // pair (arg - 1, arg).  Statements that share a register sit at least two statements apart (hipcc puts an s_nop between
                 // closer ones): four rotating t registers and sign-bit shift registers, the minimum two elements behind.
                 if constexpr (arg == 1) asm volatile("v_min_u32 %0, %1, %2" : "=v"(mm) : "v"(tt[0]), "v"(tt[1]));
                 else asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(mm) : "v"(tt[(arg - 1) & 3]), "v"(tt[arg & 3]));
             } else if constexpr (op.kind == OP_DSW) {
-                constexpr int o4 = (arg & 1) * 4;
-                const f32x4 vv = {vs[o4], vs[o4 + 1], vs[o4 + 2], vs[o4 + 3]};
-                lds_write128<(arg >> 1) * SLAB_HALF + (arg & 1) * 32>(slab_w, vv);
+                // quad `arg` of the job (accumulators 4 arg .. 4 arg + 3) times scale -> the slab, one asm statement: products in a scratch
+                // quad (two in turn: the LDS store is still reading its data registers when the next quad's first product is issued
+                // right behind it, and nothing interlocks an asm store's sources against an asm VALU write).  scale == 1 (one head, bf16
+                // or un-prescaled fp16 operands): the accumulator quad goes to the slab as it is.
+                const unsigned wa = (arg & 1) ? slab_w1 : slab_w0;
+                const f32x16& x = acc[Q][rb];
+#ifndef LAFF_STRIP_NOSLAB
+                if constexpr (SCALE1) {
+                    const f32x4 q4 = {x[4 * arg], x[4 * arg + 1], x[4 * arg + 2], x[4 * arg + 3]};
+                    lds_write128<(arg >> 1) * 64 + rb * SLAB_JOB>(wa, q4);
+                } else {
+                    // (fixed scratch registers named as clobbers: an asm operand cannot address the elements of a register quad)
+                    const float sc = scale;
+                    if constexpr ((arg & 1) == 0)
+                        asm volatile("v_mul_f32 v248, %5, %0\n\tv_mul_f32 v249, %5, %1\n\tv_mul_f32 v250, %5, %2\n\tv_mul_f32 v251, %5, %3\n\t"
+                                     "ds_write_b128 %4, v[248:251] offset:%6"
+                                     :: "v"(x[4 * arg]), "v"(x[4 * arg + 1]), "v"(x[4 * arg + 2]), "v"(x[4 * arg + 3]), "v"(wa), "s"(sc),
+                                        "n"((arg >> 1) * 64 + rb * SLAB_JOB) : "v248", "v249", "v250", "v251", "memory");
+                    else
+                        asm volatile("v_mul_f32 v252, %5, %0\n\tv_mul_f32 v253, %5, %1\n\tv_mul_f32 v254, %5, %2\n\tv_mul_f32 v255, %5, %3\n\t"
+                                     "ds_write_b128 %4, v[252:255] offset:%6"
+                                     :: "v"(x[4 * arg]), "v"(x[4 * arg + 1]), "v"(x[4 * arg + 2]), "v"(x[4 * arg + 3]), "v"(wa), "s"(sc),
+                                        "n"((arg >> 1) * 64 + rb * SLAB_JOB) : "v252", "v253", "v254", "v255", "memory");
+                }
+#endif
             } else if constexpr (op.kind == OP_CHK) {
                 // in the band <=> 0 <= t <= hi - lo; the test here may only be WIDER than the band (laff_rank_resolve applies the exact
                 // one to what is dumped).  Rows beyond the matrix have lo = hi = inf: w is NaN, nothing passes.
                 const float w = (thr_hi[rb] - thr_lo[rb]) * 1.000002f + 1e-30f;
                 const bool hit = w >= 0.0f && mm <= __float_as_uint(w);           // (mm: unsigned minimum of the bits of the job's 16 t values)
+#ifdef LAFF_STRIP_NOCHK
+                if (false) {
+#else
                 if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {                      // a third of the jobs at C4 (fp16 operands)
-                    const int c32 = cbp * CB;
-                    const int o = gtc[rb] - c32;                                     // the ground-truth column inside this lane's 16?
-                    const bool gt_mine = (unsigned)o < 32u && ((o >> 2) & 1) == hh;
-                    const unsigned gi = gt_mine ? (unsigned)((o >> 3) * 4 + (o & 3)) : 16u;
-                    dump_group(hit, row_w + rb * 32 + l31, c32 + 4 * hh, thr_lo[rb], thr_hi[rb], 0xffffu, gi, acc[Q][rb]);
+#endif
+                    dump_group(hit, row_w + rb * 32 + l31, cbp * CB + 4 * hh, thr_lo[rb], thr_hi[rb], 0xffffu, gtc[rb], acc[Q][rb]);
                 }
             } else if constexpr (op.kind == OP_CNT) {
-                cnt[rb] += __builtin_popcount((sh[0] & 0xfu) | ((sh[1] & 0xfu) << 4) | ((sh[2] & 0xfu) << 8) | ((sh[3] & 0xfu) << 12));
+                cnt[rb] += __builtin_popcount(sh[0]) + __builtin_popcount(sh[1]) + __builtin_popcount(sh[2]) + __builtin_popcount(sh[3]);
             } else if constexpr (op.kind == OP_DSR) {
-                lds_read128<(arg >> 1) * SLAB_HALF + (arg & 1) * 16 * SLAB_PITCH * 4>(rr[arg & 1], slab_r);
+#ifndef LAFF_STRIP_NOSLAB
+                // (the empty statement keeps rr[arg] allocated from its store to here: hipcc, which does not know that statement is a
+                // store, handed the registers to the very next instruction while the store was still reading them)
+                asm volatile("" ::"v"(rr[arg]));
+                lds_read128<arg * 1024 + rb * SLAB_JOB>(rr[arg], slab_r);
+#endif
             } else if constexpr (op.kind == OP_WAITR) {
                 wait_lgkm<PLAN.wait_r[rb][arg]>();
             } else if constexpr (op.kind == OP_STG) {
 #ifndef LAFF_STRIP_NOSTG
-                // (locals: a variable named only in an asm operand of a generic lambda is not captured)
-                unsigned& sa_ = sa[arg & 1];       // (alternating address registers: same reason as the two product quads)
-                const unsigned ro = (unsigned)(2 * rb + (arg & 1)) * ld16, vb = voff_base;
-                const u32x4 rs = rsrcSb, data = rr[arg & 1];
-                // s_nop behind the store: a 16-byte store reads its data registers for a few cycles after issue, hipcc (which does not
-                // know this is a store) may hand them to the very next instruction -- seen: the next address add landing in lanes 12..15
-                asm volatile("v_add_u32 %0, %1, %2\n\tbuffer_store_dwordx4 %3, %0, %4, 0 offen offset:%5 nt\n\ts_nop 1"
-                             : "=&v"(sa_) : "s"(ro), "v"(vb), "v"(data), "s"(rs), "n"((arg >> 1) * 64) : "memory");
+                // (locals: a variable named only in an asm operand of a generic lambda is not captured.)  s_nop behind the store: a
+                // 16-byte store reads its data registers for a few cycles after issue, hipcc (which does not know this is a store) may
+                // hand them to the very next instruction -- seen: an address add landing in lanes 12..15 of the stored data
+                const unsigned vo = voffs[4 * rb + arg];
+                const u32x4 rs = rsrcSb;
+                const u32x4& data = rr[arg];
+#ifndef LAFF_STRIP_STFLAVOR
+#define LAFF_STRIP_STFLAVOR "sc0 sc1 nt"      // (write-through + streaming: 2 % over "nt", 20 % over plain at C4)
+#endif
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen " LAFF_STRIP_STFLAVOR :: "v"(data), "v"(vo), "s"(rs) : "memory");
 #endif
             }
         };
@@ -710,9 +755,9 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                             thr_lo[rb] = lo; thr_hi[rb] = hi;
                         }
                     }
-                } else {
+                } else if constexpr ((J & 1) == 0) {
 #if !(LAFF_STRIP_ABL & 1)
-                    wait_lgkm<PLAN.wait_frag[J]>();
+                    wait_lgkm<PLAN.wait_frag[J]>();       // (for sub-steps J and J + 1; the barrier's wait covers BAR_J and BAR_J + 1)
 #endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -787,18 +832,21 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
     }
     m0_set(m0_keep);
     if constexpr (BANDED) {
-        if (lane == 0) ((gu32*)pPairs)[4 + wave_global] = wcount < seg ? wcount : seg;
+        if (lane == 0 && cur_chunk < NCH) ((gu32*)pPairs)[4 + cur_chunk] = cur_n;        // close this wave's last chunk
     }
 #undef STAMP
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
-int g_strip_mode = 0;        // LAFF_STRIP (read when a ctx is created): 0 = never (default while the kernel is being tuned), 1 = when eligible
+int g_strip_mode = 1;        // LAFF_STRIP (read when a ctx is created): 0 = never, 1 = where it is the faster kernel (default), 2 = wherever it can run
 int g_strip_map = 1;         // LAFF_STRIP_MAP: 0 = ranges to workgroups in order, 1 = grouped by column phase per XCD
 
 bool sim_strip_eligible(const GemmArgs& a, int mode, bool aligned) {
     if (g_strip_mode == 0) return false;
     if (mode != GEMM_F16 && mode != GEMM_BF16) return false;
+    // bf16 bands are 8 x wider: at C4 nearly every 32 x 32 job has a score inside its band and takes the dump path, which the tiled
+    // kernel does faster (0.48 vs 0.68 ms count-only) -- bf16 operands come here only when asked for
+    if (mode == GEMM_BF16 && g_strip_mode < 2) return false;
     if (!aligned || a.nseg != 1 || a.K != 512 || a.ldR != 512 || a.ldC != 512) return false;
     if (a.s_gt && !a.s_gt64) return false;                               // the legacy approximate count stays on the tiled kernel
     if (a.count && !a.s_gt64) return false;
@@ -806,7 +854,9 @@ bool sim_strip_eligible(const GemmArgs& a, int mode, bool aligned) {
     if ((long)a.nC * KBYTES >= (1ll << 32) || (a.nC + 63) / 64 > STRIP_MAX_GROUPS) return false;
     if (a.pairs && (16ull + 8ull * a.pair_cap) >= (1ull << 32)) return false;
     const long units = (long)((a.nR + SR - 1) / SR) * ((a.nC + CB - 1) / CB);
-    return units >= 8L * g_num_cus;                                      // a few column blocks per CU at least
+    // measured against the tiled kernel (fp16, count-only / with scores): 40 x 63 units 0.043 / 0.058 vs 0.036 / 0.050 ms, 20 x 157 equal /
+    // 0.069 vs 0.063, 79 x 125 0.097 / 0.135 vs 0.107 / 0.140, 157 x 313 (C4) 0.359 / 0.496 vs 0.464 / 0.571, 391 x 313 0.858 / 1.176 vs 1.124 / 1.387
+    return units >= (g_strip_mode >= 2 ? 8L : 24L) * g_num_cus;
 }
 
 hipError_t launch_sim_strip(const GemmArgs& a, int mode, hipStream_t st) {
@@ -835,26 +885,29 @@ hipError_t launch_sim_strip(const GemmArgs& a, int mode, hipStream_t st) {
     }
     const bool banded = a.s_gt64 != nullptr && a.count != nullptr;
     const bool hs = a.out != nullptr;
-#define LAFF_STRIP_LAUNCH(M, BD, HS)                                                                                          \
+#define LAFF_STRIP_LAUNCH(M, BD, HS, S1)                                                                                      \
     do {                                                                                                                      \
         static bool attr = false;                                                                                             \
         if (!attr) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute((const void*)sim_strip_kernel<M, BD, HS>,                                      \
+            hipError_t e = hipFuncSetAttribute((const void*)sim_strip_kernel<M, BD, HS, S1>,                                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);                             \
             if (e != hipSuccess) return e;                                                                                    \
             attr = true;                                                                                                      \
         }                                                                                                                     \
-        hipLaunchKernelGGL((sim_strip_kernel<M, BD, HS>), dim3((unsigned)G), dim3(256), SMEM, st, s);                         \
+        hipLaunchKernelGGL((sim_strip_kernel<M, BD, HS, S1>), dim3((unsigned)G), dim3(256), SMEM, st, s);                     \
     } while (0)
-    if (mode == GEMM_F16) {
-        if (banded && hs) LAFF_STRIP_LAUNCH(GEMM_F16, true, true);
-        else if (banded) LAFF_STRIP_LAUNCH(GEMM_F16, true, false);
-        else LAFF_STRIP_LAUNCH(GEMM_F16, false, true);
-    } else {
-        if (banded && hs) LAFF_STRIP_LAUNCH(GEMM_BF16, true, true);
-        else if (banded) LAFF_STRIP_LAUNCH(GEMM_BF16, true, false);
-        else LAFF_STRIP_LAUNCH(GEMM_BF16, false, true);
-    }
+#define LAFF_STRIP_MODE(M)                                                                                                    \
+    do {                                                                                                                      \
+        if (banded && hs && s1) LAFF_STRIP_LAUNCH(M, true, true, true);                                                       \
+        else if (banded && hs) LAFF_STRIP_LAUNCH(M, true, true, false);                                                       \
+        else if (banded) LAFF_STRIP_LAUNCH(M, true, false, false);                                                            \
+        else if (s1) LAFF_STRIP_LAUNCH(M, false, true, true);                                                                 \
+        else LAFF_STRIP_LAUNCH(M, false, true, false);                                                                        \
+    } while (0)
+    const bool s1 = a.scale == 1.0f;
+    if (mode == GEMM_F16) LAFF_STRIP_MODE(GEMM_F16);
+    else LAFF_STRIP_MODE(GEMM_BF16);
+#undef LAFF_STRIP_MODE
 #undef LAFF_STRIP_LAUNCH
     return hipGetLastError();
 }

@@ -43,6 +43,14 @@ def _context(device):
     return lib, h
 
 
+def reset_contexts():
+    """Destroys the cached laff_ctx handles; the next call creates fresh ones (the LAFF_* environment knobs are read then)."""
+    lib = _lib.load()
+    for h in _ctx.values():
+        lib.laff_ctx_destroy(h)
+    _ctx.clear()
+
+
 def _dev(t, name, dtype=torch.float32):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError('%s must be a CUDA (ROCm) tensor: laff_amd has no CPU path' % name)
@@ -499,7 +507,7 @@ class RankState:
         self.Et, self.Ev, self.T, self.V, self.heads, self.gt_col, self.col0 = Et, Ev, T, V, heads, gt_col, col0
         self.s_gt64, self.band_t, self.band_v, self.count, self.pairs, self.pair_cap = s_gt64, band_t, band_v, count, pairs, pair_cap
 
-    GROUP_WORDS = 24      # the strip kernel's list (sim_strip.hip): one dumped group of 16 accumulators per entry
+    GROUP_WORDS, GROUP_CHUNK = 24, 64      # the strip kernel's list (sim_strip.hip): entries of 24 words in chunks of 64
 
     def _header(self):
         h = self.pairs[:4].cpu().tolist()
@@ -510,9 +518,9 @@ class RankState:
         diagnostics only.  Two list layouts (the header's third word tells them apart):
           tiled kernel: header {overflow count, overflow flag, A, chunk}, A slots of per-wavefront segments (unused slots have row
                         0xffffffff), then the overflow pairs;
-          strip kernel: header {overflow count, overflow flag, NW | 1 << 31, seg}, NW per-wavefront entry counts, then entries
-                        {row, colbase, lo, hi | mask16, gt element, 0, 0 | 16 raw accumulators}: the pairs are the listed elements
-                        with lo <= x <= hi (the test laff_rank_resolve applies)."""
+          strip kernel: header {chunks taken, overflow flag, NW | 1 << 31, NCH}, NCH per-chunk entry counts, then NCH chunks of 64
+                        entries {row, colbase, lo, hi | mask16, the row's ground-truth column, 0, 0 | 16 raw accumulators}: the
+                        pairs are the listed elements with lo <= x <= hi (the test laff_rank_resolve applies)."""
         return int(self.pair_indices().shape[0]), bool(self._header()[1])
 
     def pair_indices(self):
@@ -523,24 +531,21 @@ class RankState:
             seg = self.pairs[4:4 + 2 * reg_a].view(-1, 2)
             over = self.pairs[4 + 2 * reg_a:4 + 2 * (reg_a + min(n_over, max(self.pair_cap - reg_a, 0)))].view(-1, 2)
             return torch.cat([seg[seg[:, 0] != -1], over]).long()
-        nw, seg, W = third & 0x7fffffff, fourth, self.GROUP_WORDS
-        cnt_words = (nw + 3) & ~3
-        e_total = max(2 * self.pair_cap - cnt_words, 0) // W
-        counts = self.pairs[4:4 + nw].long().clamp(max=seg)
-        ent = self.pairs[4 + cnt_words:4 + cnt_words + e_total * W].view(-1, W)
-        live = torch.zeros(e_total, dtype=torch.bool, device=ent.device)
-        if nw * seg:
-            live[:nw * seg] = (torch.arange(seg, device=ent.device)[None, :] < counts[:, None]).reshape(-1)
-        live[nw * seg:nw * seg + min(n_over, max(e_total - nw * seg, 0))] = True
+        nw, nch, W, CH = third & 0x7fffffff, fourth, self.GROUP_WORDS, self.GROUP_CHUNK
+        cnt_words = (nch + 3) & ~3
+        nchunks = min(nw + n_over, nch)                   # (header word 0: chunks taken from the pool)
+        counts = self.pairs[4:4 + nchunks].long().clamp(max=CH)
+        ent = self.pairs[4 + cnt_words:4 + cnt_words + nchunks * CH * W].view(nchunks, CH, W)
+        live = torch.arange(CH, device=ent.device)[None, :] < counts[:, None]
         ent = ent[live]
         if ent.shape[0] == 0:
             return torch.zeros((0, 2), dtype=torch.int64, device=ent.device)
         e = torch.arange(16, device=ent.device)
         x = ent[:, 8:24].view(torch.float32)
         lo, hi = ent[:, 2:3].view(torch.float32), ent[:, 3:4].view(torch.float32)
-        listed = ((ent[:, 4:5] >> e[None, :]) & 1).bool() & (e[None, :] != ent[:, 5:6]) & (x >= lo) & (x <= hi)
         rows = ent[:, 0:1].long().expand(-1, 16)
         cols = ent[:, 1:2].long() + 8 * (e >> 2)[None, :] + (e & 3)[None, :]
+        listed = ((ent[:, 4:5] >> e[None, :]) & 1).bool() & (cols != ent[:, 5:6].long()) & (x >= lo) & (x <= hi)
         return torch.stack([rows[listed], cols[listed]], dim=1)
 
 

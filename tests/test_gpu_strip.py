@@ -1,0 +1,148 @@
+"""The strip form of the K = 512 similarity GEMM (laff_amd/csrc/sim_strip.hip: one wavefront per SIMD holding 64 text rows in
+registers, video blocks streamed through LDS) against the tiled kernel, the oracle and float64 ranks.  Both kernels sit behind the
+same entry points (laff_sim_gemm / laff_sim_gemm_banded, include/laff_hip.h); LAFF_STRIP picks: 0 = tiled only, 1 = strip where it
+is faster (default), 2 = strip wherever it can run."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import laff_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture
+def strip_mode():
+    from laff_amd import ops
+
+    def set_mode(m):
+        os.environ['LAFF_STRIP'] = str(m)
+        ops.reset_contexts()
+    yield set_mode
+    os.environ.pop('LAFF_STRIP', None)
+    ops.reset_contexts()
+
+
+def _embeddings(Nt, Nv, noise, seed, H=1, d=512):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    z = torch.randn(Nv, 48, generator=g, device=DEV)
+    P = torch.randn(48, H * d, generator=g, device=DEV)
+    gt = (torch.arange(Nt, device=DEV) * 7919 % Nv).to(torch.int32)
+    Ev = (z @ P + noise * torch.randn(Nv, H * d, generator=g, device=DEV)).reshape(Nv, H, d).contiguous()
+    Et = (z[gt.long()] @ P + noise * torch.randn(Nt, H * d, generator=g, device=DEV)).reshape(Nt, H, d).contiguous()
+    return Et, Ev, gt
+
+
+def _fp64_count(Et, Ev, gt):
+    t, v = Et.double(), Ev.double()
+    t = t / (t.pow(2).sum(-1, keepdim=True).sqrt() + (1e-13 + 1e-14))
+    v = v / (v.pow(2).sum(-1, keepdim=True).sqrt() + (1e-13 + 1e-14))
+    out = torch.empty(Et.shape[0], dtype=torch.int32, device=Et.device)
+    for a in range(0, Et.shape[0], 4096):
+        S = torch.einsum('thd,vhd->tv', t[a:a + 4096], v) / Et.shape[1]
+        g = gt[a:a + 4096].long()
+        ab = S > S.gather(1, g[:, None])
+        ab[torch.arange(ab.shape[0], device=S.device), g] = False
+        out[a:a + 4096] = ab.sum(1).to(torch.int32)
+    return out
+
+
+def _run(ops, Et, Ev, gt, prec, want_scores, ldo=None, pair_cap=None, prescale=None):
+    T, V = ops.pack_rows(Et, True, 1e-13, prec, prescale), ops.pack_rows(Ev, True, 1e-13, prec, prescale)
+    st = ops.rank_prepare(Et, Ev, T, V, gt, 0, pair_cap)
+    out = None
+    if want_scores and ldo is not None:
+        out = torch.full((Et.shape[0], ldo), -7.0, device=DEV)[:, :Ev.shape[0]]
+    S = ops.sim_gemm_banded(st, want_scores, out=out)
+    ops.rank_resolve(st, S)
+    torch.cuda.synchronize()
+    return S, st
+
+
+@pytest.mark.parametrize('prec,prescale', [('fp16', None), ('fp16', 1.0), ('bf16', None)])
+def test_strip_equals_tiled_at_c4(strip_mode, prec, prescale):
+    """40000 x 10000 (BASELINE config C4): scores bit-identical to the tiled kernel's, same band pairs, counts equal to the float64
+    ranks; prescale 1 is the scale == 1 instantiation (no multiply in the epilogue)."""
+    from laff_amd import ops
+    Et, Ev, gt = _embeddings(40000, 10000, 9.0, 3)
+    want = _fp64_count(Et, Ev, gt)
+    strip_mode(0)
+    S0, st0 = _run(ops, Et, Ev, gt, prec, True, prescale=prescale)
+    p0, c0 = st0.pair_indices(), st0.count.clone()
+    assert torch.equal(c0, want)
+    strip_mode(2)
+    S1, st1 = _run(ops, Et, Ev, gt, prec, True, prescale=prescale)
+    assert not st1.listed_pairs()[1]
+    assert int(st1._header()[2]) >> 31 == 1, 'the strip kernel did not run'
+    assert torch.equal(S1, S0)
+    assert torch.equal(st1.count, want)
+    assert set(map(tuple, st1.pair_indices().tolist())) == set(map(tuple, p0.tolist()))
+    _, st2 = _run(ops, Et, Ev, gt, prec, False, prescale=prescale)
+    assert int(st2._header()[2]) >> 31 == 1
+    assert torch.equal(st2.count, want)
+    # scores alone (laff_sim_gemm)
+    T, V = ops.pack_rows(Et, True, 1e-13, prec, prescale), ops.pack_rows(Ev, True, 1e-13, prec, prescale)
+    Sp1 = ops.sim_gemm(T, V)
+    strip_mode(0)
+    assert torch.equal(ops.sim_gemm(T, V), Sp1)
+
+
+@pytest.mark.parametrize('Nt,Nv,ldo', [(2309, 8200, 8200), (2305, 8197, 8200), (4099, 4133, 4160), (2049, 8193, 8196)])
+def test_strip_ragged_shapes_vs_oracle(strip_mode, Nt, Nv, ldo):
+    """Partial last strip, partial last column block, padded score rows (the padding must stay untouched), checked against the oracle:
+    scores within the fp16 operand bound of oracle/laff_oracle.txt2vis_matrix_f64 (model/model.py:1003-1016), counts exactly its ranks."""
+    from laff_amd import ops
+    Et, Ev, gt = _embeddings(Nt, Nv, 6.0, Nt + Nv)
+    S64 = O.txt2vis_matrix_f64(Et.cpu().numpy(), Ev.cpu().numpy())
+    want = O.count_ranks(S64, gt.cpu().numpy()) - 1
+    strip_mode(2)
+    S1, st1 = _run(ops, Et, Ev, gt, 'fp16', True, ldo=ldo)
+    assert int(st1._header()[2]) >> 31 == 1, 'the strip kernel did not run'
+    assert not st1.listed_pairs()[1]
+    np.testing.assert_array_equal(st1.count.cpu().numpy(), want)
+    assert float(np.abs(S1.cpu().numpy().astype(np.float64) - S64).max()) < 5e-4          # include/laff_hip.h: LAFF_PREC_FP16
+    if ldo > Nv:
+        assert bool((S1._base[:, Nv:] == -7.0).all()) if S1._base is not None else True
+    strip_mode(0)
+    S0, st0 = _run(ops, Et, Ev, gt, 'fp16', True, ldo=ldo)
+    assert int(st0._header()[2]) >> 31 == 0
+    assert torch.equal(S0, S1)
+    strip_mode(2)
+    _, st2 = _run(ops, Et, Ev, gt, 'fp16', False)
+    np.testing.assert_array_equal(st2.count.cpu().numpy(), want)
+
+
+def test_strip_list_overflow_is_flagged_and_poisons(strip_mode):
+    """A dump list too small for the band: the flag is raised, count[0] is poisoned (include/laff_hip.h) and rank_metrics refuses."""
+    from laff_amd import ops
+    Et, Ev, gt = _embeddings(8192, 8192, 0.02, 11)           # near-duplicate rows: many scores inside the band
+    strip_mode(2)
+    _, st = _run(ops, Et, Ev, gt, 'fp16', False, pair_cap=4 * (1 + 64 * 24) * 40)
+    assert int(st._header()[2]) >> 31 == 1
+    n, over = st.listed_pairs()
+    if not over:
+        pytest.skip('list did not overflow with this data (%d pairs)' % n)
+    assert int(st.count[0]) < -(1 << 25)
+    with pytest.raises(Exception):
+        ops.rank_metrics(st.count, base=1)
+    # the same data with room: exact
+    _, st_ok = _run(ops, Et, Ev, gt, 'fp16', False, pair_cap=64 << 20)
+    assert not st_ok.listed_pairs()[1]
+    assert torch.equal(st_ok.count, _fp64_count(Et, Ev, gt))
+
+
+def test_default_dispatch_takes_the_strip_kernel_at_c4_and_not_for_small_or_bf16(strip_mode):
+    from laff_amd import ops
+    strip_mode(1)
+    Et, Ev, gt = _embeddings(40000, 10000, 9.0, 5)
+    _, st = _run(ops, Et, Ev, gt, 'fp16', False)
+    assert int(st._header()[2]) >> 31 == 1
+    _, st = _run(ops, Et, Ev, gt, 'bf16', False)
+    assert int(st._header()[2]) >> 31 == 0
+    Et, Ev, gt = _embeddings(3000, 2000, 9.0, 5)
+    _, st = _run(ops, Et, Ev, gt, 'fp16', False)
+    assert int(st._header()[2]) >> 31 == 0
+    assert torch.equal(st.count, _fp64_count(Et, Ev, gt))
