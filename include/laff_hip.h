@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 11
+#define LAFF_ABI_VERSION 12
 
 enum {
     LAFF_OK = 0,
@@ -280,6 +280,18 @@ int laff_rank_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, cons
  * grp_off[Nv+1] / grp_idx[Nt]: CSR of texts grouped by owner column (local). */
 int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* grp_off,
                    const int* grp_idx, int max_group, int* count);
+
+/* The same count made EXACT on the outputs of the exact-rank pipeline (replaces the column argsort of /root/reference/predictor.py:262-270
+ * with positions that do not depend on the operand precision of the GEMM):
+ *   count[t] = #{ t' != t : exact(t', v) > exact(t, v) },  exact() = the fp64 cosine of the fp32 embeddings (laff_rank_prepare).
+ * S must be what laff_sim_gemm_banded (+ laff_rank_resolve) wrote for these operands: every entry within band_t[t'] + band_v[v] of
+ * exact(t', v).  Entries further than that from a caption's threshold s_gt64[t] are decided on S; the others are listed as {t', v, t}
+ * (3 words each behind a 4-word header {entries wanted, overflow flag, 0, 0}; list_cap entries) and re-scored in fp64 from Et / Ev.
+ * count [Nt] is overwritten (0 for texts whose video is not a column of this S).  list[1] != 0 afterwards: the list was too small,
+ * count is not valid -- call again with list_cap >= list[0]. */
+int laff_v2t_count_exact(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx,
+                         int max_group, const float* Et, const float* Ev, int H, int d, const double* s_gt64,
+                         const float* band_t, const float* band_v, int* count, unsigned* list, unsigned list_cap);
 
 /* ---- result lists (predictor.txt2video_write_to_file, predictor.py:53-88): for every row the K best columns, score
  * descending (ties: larger column first = a stable ascending argsort read backwards), instead of a full-matrix argsort.

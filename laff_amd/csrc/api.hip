@@ -670,6 +670,28 @@ int laff_v2t_count(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const
     return LAFF_OK;
 }
 
+int laff_v2t_count_exact(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx,
+                         int max_group, const float* Et, const float* Ev, int H, int d, const double* s_gt64,
+                         const float* band_t, const float* band_v, int* count, unsigned* list, unsigned list_cap) {
+    CHECK_CTX(ctx);
+    if (Nt == 0 || Nv == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
+    if (!S || !grp_off || !grp_idx || !count || !Et || !Ev || !s_gt64 || !band_t || !band_v || !list)
+        return fail(LAFF_E_ARG, "laff_v2t_count_exact: null argument");
+    if (Nt < 0 || Nv < 0 || lds < Nv || max_group < 0 || H < 1 || d < 4 || (d & 3))
+        return fail(LAFF_E_SHAPE, "laff_v2t_count_exact: bad shape (Nt=%d Nv=%d lds=%d H=%d d=%d: d must be a multiple of 4)", Nt, Nv, lds, H, d);
+    if (!aligned16(Et) || !aligned16(Ev)) return fail(LAFF_E_ALIGN, "laff_v2t_count_exact: embeddings must be 16-byte aligned");
+    if (list_cap < 1) return fail(LAFF_E_SHAPE, "laff_v2t_count_exact: list_cap must be >= 1");
+    DeviceGuard g(ctx->device);
+    if (max_group == 0) {
+        HIP_TRY(hipMemsetAsync(count, 0, (size_t)Nt * sizeof(int), ctx->stream));
+        HIP_TRY(hipMemsetAsync(list, 0, 16, ctx->stream));
+        return LAFF_OK;
+    }
+    HIP_TRY(laff::launch_v2t_count_exact(S, Nt, Nv, lds, grp_off, grp_idx, max_group, Et, Ev, H, d, s_gt64, band_t, band_v, count, list,
+                                         list_cap, ctx->stream));
+    return LAFF_OK;
+}
+
 int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
                     const int* gt_col, int col0, float* s_gt, int* zero_count) {
     CHECK_CTX(ctx);

@@ -167,5 +167,8 @@ hipError_t launch_rank_count(const float* S, int Nt, int Nv, int lds, const int*
 hipError_t launch_topk_rows(const float* S, int Nt, int Nv, int lds, int K, int* idx_out, float* val_out, hipStream_t st);
 hipError_t launch_v2t_count(const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx,
                             int max_group, int* count, hipStream_t st);
+hipError_t launch_v2t_count_exact(const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx, int max_group,
+                                  const float* Et, const float* Ev, int H, int d, const double* s_gt64, const float* band_t,
+                                  const float* band_v, int* count, unsigned* list, unsigned cap, hipStream_t st);
 
 }  // namespace laff

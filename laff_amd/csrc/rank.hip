@@ -678,6 +678,130 @@ hipError_t launch_rank_count(const float* S, int Nt, int Nv, int lds, const int*
     return hipGetLastError();
 }
 
+// ---- exact video-to-text positions (predictor.py:262-270 ranks every column of the score matrix) ---------------------------------
+// count[t] = #{ t' != t : exact(t', v) > exact(t, v) },  v = the owner column of t, on a score matrix S whose entries are within
+// band_t[t'] + band_v[v] of exact(t', v) (what laff_sim_gemm_banded / laff_rank_resolve leave behind; the bound is laff_rank_prepare's).
+// A column is compared with the exact scores of ITS captions (s_gt64, one threshold per caption, G per pass): an entry further than
+// its band from a threshold is decided on S; the others (a few per caption) go to a list {t', v, t} and are re-scored in fp64 from
+// the fp32 embeddings by v2t_resolve_kernel with the arithmetic of exact_cos(), i.e. of the text-to-video ranks.
+// Grid (column blocks of 32, row chunks): every block adds its partial counts (count is cleared by the caller).
+template <int G>
+__global__ __launch_bounds__(256) void v2t_band_count_kernel(const float* __restrict__ S, int Nt, int Nv, long lds,
+                                                             const int* __restrict__ grp_off, const int* __restrict__ grp_idx,
+                                                             const double* __restrict__ s_gt64, const float* __restrict__ band_t,
+                                                             const float* __restrict__ band_v, int* __restrict__ count,
+                                                             unsigned* __restrict__ list, unsigned cap, int pass, int rows_per_block) {
+    constexpr int CT = 32;
+    __shared__ float thr[CT][G + 1];
+    __shared__ int own[CT][G + 1];
+    __shared__ int cnts[8][CT][G + 1];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * CT + cx;
+    const bool col_ok = c < Nv;
+    int g0 = 0, gn = 0;
+    if (col_ok) {
+        g0 = grp_off[c] + pass * G;
+        gn = min(max(grp_off[c + 1] - g0, 0), G);
+    }
+    if (ry == 0) {
+        for (int i = 0; i < G; ++i) {
+            const int t = (i < gn) ? grp_idx[g0 + i] : -1;
+            own[cx][i] = t;
+            thr[cx][i] = (t >= 0) ? (float)s_gt64[t] : INFINITY;          // (the rounding is inside the band: rank.hip, c_acc)
+        }
+    }
+    __syncthreads();
+    float th[G];
+    int ow[G], cn[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        th[i] = thr[cx][i];
+        ow[i] = own[cx][i];
+        cn[i] = 0;
+    }
+    if (col_ok && gn > 0) {
+        const float bv = band_v[c];
+        const int r_end = min(Nt, ((int)blockIdx.y + 1) * rows_per_block);
+        for (int r = (int)blockIdx.y * rows_per_block + ry; r < r_end; r += 8) {
+            const float v = S[(long)r * lds + c];
+            const float e = (band_t[r] + bv) * 1.000001f + 1e-9f;          // (fp32 roundings of the sum and of v - th)
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const float dlt = v - th[i];
+                cn[i] += (dlt > e);
+                if (fabsf(dlt) <= e && r != ow[i] && ow[i] >= 0) {
+                    const unsigned slot = atomicAdd(list, 1u);
+                    if (slot < cap) {
+                        list[4 + 3 * (size_t)slot] = (unsigned)r;
+                        list[5 + 3 * (size_t)slot] = (unsigned)c;
+                        list[6 + 3 * (size_t)slot] = (unsigned)ow[i];
+                    } else {
+                        list[1] = 1u;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) cnts[ry][cx][i] = cn[i];
+    __syncthreads();
+    if (ry == 0 && col_ok) {
+        for (int i = 0; i < gn; ++i) {
+            int tot = 0;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) tot += cnts[y][cx][i];
+            if (tot) atomicAdd(count + grp_idx[g0 + i], tot);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void v2t_resolve_kernel(const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d,
+                                                          const double* __restrict__ s_gt64, int* __restrict__ count,
+                                                          const unsigned* __restrict__ list, unsigned cap) {
+    const int sl = threadIdx.x & (RG - 1);
+    const long K = (long)H * d;
+    const unsigned n = min(list[0], cap);
+    const unsigned group = (blockIdx.x * 256u + threadIdx.x) / RG, ngroups = gridDim.x * (256u / RG);
+    const unsigned trips = (n + ngroups - 1) / ngroups;
+    for (unsigned it = 0; it < trips; ++it) {                                 // wave-uniform trip count (the shuffles of exact_cos)
+        const unsigned j = it * ngroups + group;
+        const bool ok = j < n;
+        const unsigned k = ok ? j : n - 1;
+        const unsigned r = list[4 + 3 * (size_t)k], c = list[5 + 3 * (size_t)k], t = list[6 + 3 * (size_t)k];
+        const double ex = exact_cos(Et + (long)r * K, Ev + (long)c * K, H, d, sl);
+        if (ok && sl == 0 && ex > s_gt64[t]) atomicAdd(count + t, 1);
+    }
+}
+
+hipError_t launch_v2t_count_exact(const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx, int max_group,
+                                  const float* Et, const float* Ev, int H, int d, const double* s_gt64, const float* band_t,
+                                  const float* band_v, int* count, unsigned* list, unsigned cap, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(count, 0, (size_t)Nt * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(list, 0, 16, st);
+    if (e != hipSuccess) return e;
+    const unsigned gx = (unsigned)((Nv + 31) / 32);
+    // row chunks: enough blocks for four rounds of the chip, at least 256 rows each
+    int gy = (int)std::min<long>(std::max<long>(1, (8L * g_num_cus + gx - 1) / gx), std::max<long>(1, Nt / 256));
+    const int rows_per_block = ((Nt + gy - 1) / gy + 7) & ~7;
+    gy = (Nt + rows_per_block - 1) / rows_per_block;
+    const int G = max_group <= 4 ? 4 : (max_group <= 8 ? 8 : 16);
+    const int passes = (max_group + G - 1) / G;
+    for (int p = 0; p < passes; ++p) {
+#define LAFF_V2T(GG)                                                                                                             \
+    hipLaunchKernelGGL((v2t_band_count_kernel<GG>), dim3(gx, (unsigned)gy), dim3(256), 0, st, S, Nt, Nv, (long)lds, grp_off, grp_idx,    \
+                       s_gt64, band_t, band_v, count, list, cap, p, rows_per_block)
+        switch (G) {
+            case 4: LAFF_V2T(4); break;
+            case 8: LAFF_V2T(8); break;
+            default: LAFF_V2T(16); break;
+        }
+#undef LAFF_V2T
+    }
+    hipLaunchKernelGGL(v2t_resolve_kernel, dim3((unsigned)(4 * g_num_cus)), dim3(256), 0, st, Et, Ev, H, d, s_gt64, count, list, cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_v2t_count(const float* S, int Nt, int Nv, int lds, const int* grp_off, const int* grp_idx,
                             int max_group, int* count, hipStream_t st) {
     const unsigned grid = (unsigned)((Nv + 31) / 32);

@@ -648,7 +648,8 @@ class W2VVPP(nn.Module):
         When every caption id names its video the reference's way (`txt_id.split('#')[0]` in vis_ids, predictor.py:241), S is
         produced by the exact-rank pipeline: the text->video ranks counted from it (predictor.t2v_ranks, or an argsort on the host
         as the reference does) are the ranks of the exact cosine scores whatever the operand precision; they are also kept in
-        `self.last_t2v_ranks`."""
+        `self.last_t2v_ranks`, and the pipeline's state in `self.last_rank_state` (exact video->text positions:
+        predictor.retrieval_metrics(S, txt_ids, vis_ids, state=model.last_rank_state))."""
         if measure != 'cosine':
             raise NotImplementedError("measure '%s'" % measure)
         self.eval()
@@ -675,6 +676,7 @@ class W2VVPP(nn.Module):
             if not identity:   # the reference indexes the cached embeddings BY dataset index (:1066)
                 vis_used = self.video_all_embs[torch.as_tensor(cols, device=self.video_all_embs.device)]
             self.last_t2v_ranks = None
+            self.last_rank_state = None          # ops.RankState of the exact-rank pass: predictor.retrieval_metrics(S, ..., state=) ranks V2T exactly with it
             owner = None
             if identity and len(txt_ids) and len(self.vis_ids) == vis_used.shape[0]:
                 from ..predictor import gt_columns
@@ -703,6 +705,8 @@ class W2VVPP(nn.Module):
                     raise RuntimeError('laff_amd: the pair list of the exact-rank pipeline overflowed even with split operands and an 8x '
                                        'list (%d texts x %d videos): the scores are degenerate' % (Et.shape[0], Ev.shape[0]))
                 self.last_t2v_ranks = count + 1
+                if identity:
+                    self.last_rank_state = st
             else:
                 S = self.get_txt2vis_matrix(txt_all, vis_used, measure, precision)
             if not identity:

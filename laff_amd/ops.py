@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, FcSplitProblem, Plane, check, FcFusedProblem)
 
-__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count',
+__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -718,6 +718,30 @@ def v2t_count(S, grp_off, grp_idx, max_group):
     _call('v2t_count', lib.laff_v2t_count, h, _ptr(S), S.shape[0], S.shape[1], lds, _ptr(grp_off), _ptr(grp_idx), int(max_group),
                              _ptr(count))
     return count
+
+
+def v2t_count_exact(S, st, grp_off, grp_idx, max_group, list_cap=None):
+    """laff_v2t_count_exact on the score matrix and RankState of exact_ranks (same operands, col0 == 0): int32 (Nt,) counts of texts
+    that beat caption t in the column of its video, decided with the exact fp64 scores.  Synchronises (reads the overflow flag);
+    a list that was too small is re-sized once."""
+    S, lds = _rows(S, 'S')
+    _dev(grp_off, 'grp_off', torch.int32)
+    _dev(grp_idx, 'grp_idx', torch.int32)
+    Nt, H, d = st.Et.shape
+    if tuple(S.shape) != (Nt, st.Ev.shape[0]) or st.col0 != 0:
+        raise ValueError('S %s does not belong to this RankState (%d x %d, col0 %d)' % (tuple(S.shape), Nt, st.Ev.shape[0], st.col0))
+    count = torch.empty((Nt,), device=S.device, dtype=torch.int32)
+    cap = int(list_cap) if list_cap is not None else max(1 << 16, 8 * Nt)
+    lib, h = _context(S.device)
+    for attempt in range(2):
+        lst = torch.empty((4 + 3 * cap,), device=S.device, dtype=torch.int32)
+        _call('v2t_count_exact', lib.laff_v2t_count_exact, h, _ptr(S), Nt, S.shape[1], lds, _ptr(grp_off), _ptr(grp_idx), int(max_group),
+              _ptr(st.Et), _ptr(st.Ev), H, d, _ptr(st.s_gt64), _ptr(st.band_t), _ptr(st.band_v), _ptr(count), _ptr(lst), cap)
+        wanted, overflow = [int(x) & 0xffffffff for x in lst[:2].cpu().tolist()]
+        if not overflow:
+            return count
+        cap = wanted + 1024
+    raise RuntimeError('laff_v2t_count_exact: the list of in-band pairs overflowed twice (%d wanted)' % wanted)
 
 
 def _ranks_out(r, ranks_out):

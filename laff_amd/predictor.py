@@ -36,21 +36,27 @@ def t2v_metrics(S, owner):
     return ops.rank_metrics(t2v_ranks(S, owner).to(torch.int32))
 
 
-def v2t_positions(S, owner):
-    """For every text t: 1-based position of t in the descending column of its owner video."""
+def v2t_positions(S, owner, state=None):
+    """For every text t: 1-based position of t in the descending column of its owner video.  With the RankState of the exact-rank
+    pipeline that produced S (ops.exact_ranks) the positions are those of the fp64 scores (laff_v2t_count_exact); without it they
+    are counted on S as it is."""
     owner = np.asarray(owner, dtype=np.int64)
     Nv = S.shape[1]
     order = np.argsort(owner, kind='stable').astype(np.int32)
     counts = np.bincount(owner, minlength=Nv)
     off = np.zeros(Nv + 1, dtype=np.int32)
     np.cumsum(counts, out=off[1:])
-    cnt = ops.v2t_count(S, torch.as_tensor(off, device=S.device), torch.as_tensor(order, device=S.device), int(counts.max()))
+    d_off, d_order = torch.as_tensor(off, device=S.device), torch.as_tensor(order, device=S.device)
+    if state is not None:
+        cnt = ops.v2t_count_exact(S, state, d_off, d_order, int(counts.max()))
+    else:
+        cnt = ops.v2t_count(S, d_off, d_order, int(counts.max()))
     return cnt.cpu().numpy().astype(np.int64) + 1, order, off
 
 
-def v2t_metrics(S, owner):
+def v2t_metrics(S, owner, state=None):
     """predictor.py:262-276: per video, positions of all its captions -> evaluation.eval arithmetic."""
-    pos, order, off = v2t_positions(S, owner)
+    pos, order, off = v2t_positions(S, owner, state)
     Nv = S.shape[1]
     if (np.diff(off) == 0).any():
         raise IndexError('a video has no caption: the reference fails on rank[0] (evaluation.py:99)')
@@ -71,11 +77,17 @@ def v2t_metrics(S, owner):
     return evaluation.eval_from_positions(first, ap)
 
 
-def retrieval_metrics(S, txt_ids, vis_ids):
-    """Both directions from a device score matrix, as get_predict_file reports them."""
+def retrieval_metrics(S, txt_ids, vis_ids, state=None):
+    """Both directions from a device score matrix, as get_predict_file reports them.  state: the RankState of the exact-rank pipeline
+    that produced S (ops.exact_ranks / model.retrieve); with it both directions are ranked on the fp64 scores."""
     if not isinstance(S, torch.Tensor):
         S = torch.as_tensor(np.ascontiguousarray(S, dtype=np.float32), device='cuda')
     owner = gt_columns(txt_ids, vis_ids)
+    if state is not None:
+        if not np.array_equal(state.gt_col.cpu().numpy(), owner):
+            raise ValueError('state was prepared for other ground-truth columns than txt_ids / vis_ids give')
+        t2v = ops.rank_metrics(state.count, base=1)
+        return t2v, v2t_metrics(S, owner, state)
     return t2v_metrics(S, owner), v2t_metrics(S, owner)
 
 

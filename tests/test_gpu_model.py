@@ -187,6 +187,10 @@ def test_predict_golden(golden):
     t2v16, v2t16 = predictor.retrieval_metrics(S16, out_txt, out_vis)
     np.testing.assert_allclose(t2v16, g['t2v_metrics'], rtol=0, atol=1e-9)     # all seven: the ranks are exact whatever the operands
     assert torch.equal(model.last_t2v_ranks, ranks_x3)
+    # ... and with the pipeline's state the video->text direction too (laff_v2t_count_exact): fp16 operands, the reference's 7 numbers
+    t2v16e, v2t16e = predictor.retrieval_metrics(S16, out_txt, out_vis, state=model.last_rank_state)
+    np.testing.assert_allclose(t2v16e, g['t2v_metrics'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(v2t16e, g['v2t_metrics'], rtol=0, atol=1e-9)
     heads, _, _ = model.predict_each_head(tl, vl, 'cosine')
     assert maxdiff(heads.mean(axis=0), g['scores']) <= 1e-4
 

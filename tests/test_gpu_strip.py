@@ -146,3 +146,52 @@ def test_default_dispatch_takes_the_strip_kernel_at_c4_and_not_for_small_or_bf16
     _, st = _run(ops, Et, Ev, gt, 'fp16', False)
     assert int(st._header()[2]) >> 31 == 0
     assert torch.equal(st.count, _fp64_count(Et, Ev, gt))
+
+
+def _fp64_v2t_count(Et, Ev, owner):
+    """count[t] = #{t' != t : S64[t', v] > S64[t, v]}, v = owner[t], on the float64 cosine scores (torch, column blocks)."""
+    t, v = Et.double(), Ev.double()
+    t = t / (t.pow(2).sum(-1, keepdim=True).sqrt() + (1e-13 + 1e-14))
+    v = v / (v.pow(2).sum(-1, keepdim=True).sqrt() + (1e-13 + 1e-14))
+    Nt = Et.shape[0]
+    out = torch.empty(Nt, dtype=torch.int32, device=Et.device)
+    ow = owner.long()
+    for a in range(0, Ev.shape[0], 512):
+        S = torch.einsum('thd,vhd->tv', t, v[a:a + 512]) / Et.shape[1]          # (Nt, 512)
+        mine = ((ow >= a) & (ow < a + 512)).nonzero().flatten()
+        if mine.numel() == 0:
+            continue
+        col = (ow[mine] - a)
+        thr = S[mine, col]                                                       # (n,)
+        for b in range(0, mine.numel(), 2048):
+            m, c, th = mine[b:b + 2048], col[b:b + 2048], thr[b:b + 2048]
+            ab = S[:, c] > th[None, :]                                           # (Nt, n)
+            ab[m, torch.arange(m.numel(), device=S.device)] = False
+            out[m] = ab.sum(0).to(torch.int32)
+    return out
+
+
+@pytest.mark.parametrize('prec', ['fp16', 'bf16'])
+def test_exact_v2t_positions_at_c1_shapes(strip_mode, prec):
+    """59800 captions x 2990 videos, 20 captions per video (the reference's MSR-VTT test split, BASELINE config C1): the video->text
+    counts of laff_v2t_count_exact equal those of the float64 scores with fp16 and with bf16 operands."""
+    from laff_amd import ops
+    Nv, per = 2990, 20
+    Nt = Nv * per
+    g = torch.Generator(device=DEV).manual_seed(21)
+    z = torch.randn(Nv, 48, generator=g, device=DEV)
+    P = torch.randn(48, 512, generator=g, device=DEV)
+    owner = (torch.arange(Nt, device=DEV) // per).to(torch.int32)
+    Ev = (z @ P + 7.0 * torch.randn(Nv, 512, generator=g, device=DEV)).reshape(Nv, 1, 512).contiguous()
+    Et = (z[owner.long()] @ P + 7.0 * torch.randn(Nt, 512, generator=g, device=DEV)).reshape(Nt, 1, 512).contiguous()
+    want = _fp64_v2t_count(Et, Ev, owner)
+    strip_mode(1)
+    T, V = ops.pack_rows(Et, True, 1e-13, prec), ops.pack_rows(Ev, True, 1e-13, prec)
+    S, count, st = ops.exact_ranks(Et, Ev, T, V, owner)
+    assert not st.listed_pairs()[1]
+    off = torch.arange(0, Nt + 1, per, device=DEV, dtype=torch.int32)
+    idx = torch.arange(Nt, device=DEV, dtype=torch.int32)
+    got = ops.v2t_count_exact(S, st, off, idx, per)
+    assert torch.equal(got, want)
+    assert torch.equal(ops.v2t_count_exact(S, st, off, idx, per, list_cap=64), want)          # overflow -> one retry with the wanted size
+    assert torch.equal(count, _fp64_count(Et, Ev, owner))
