@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, FcSplitProblem, Plane, check, FcFusedProblem)
 
-__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts',
+__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'topk_from_operands', 'alloc_scores', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -451,6 +451,21 @@ class Packed:
     def __init__(self, buf, N, K, precision, prescale):
         self.buf, self.N, self.K, self.precision, self.prescale = buf, N, K, precision, prescale
 
+    def rows(self, a, b):
+        """The operand of rows [a, b): a view for one-plane formats, a copy of the two plane slices for the hi/lo split formats
+        (their planes are N rows apart)."""
+        a, b = max(0, int(a)), min(self.N, int(b))
+        esz = 4 if self.precision == 'fp32' else 2
+        rb = self.K * esz
+        if self.precision in ('fp16x3', 'bf16x3'):
+            plane = self.N * rb
+            buf = torch.cat([self.buf[a * rb:b * rb], self.buf[plane + a * rb:plane + b * rb]])
+        else:
+            buf = self.buf[a * rb:b * rb]
+        if buf.data_ptr() % 16:
+            buf = buf.clone()
+        return Packed(buf, b - a, self.K, self.precision, self.prescale)
+
 
 def pack_rows(E, normalize=True, eps=1e-13, precision='fp16', prescale=None):
     """E (N, H, d) or (N, d): per-(row, head) l2norm (loss.l2norm) then conversion to the GEMM operand format."""
@@ -685,27 +700,20 @@ def _topk_call(S, K):
     return idx, val
 
 
-def topk_rows(S, K):
-    """Per row: indices (int32) and scores (fp32) of the K best columns, score descending, ties by larger index first (what the
-    reference's `np.argsort(...)[::-1][:K]` yields with a stable sort, predictor.py:53-65).  Any number of columns: a collection that
-    does not fit the kernel's LDS-resident row (~36k columns at K <= 2048) is split into column blocks, each block's K best are
-    taken, and the lists are merged by the same kernel -- block lists are laid out in ascending (score, index) order and blocks in
-    column order, so that position order equals index order among equal scores and the tie rule carries over.  K <= 8192."""
-    S, lds = _rows(S, 'S')
-    Nt, Nv = S.shape
-    K = int(K)
-    if K < 1 or K > Nv or K > 8192:
-        raise ValueError('topk_rows: need 1 <= K <= min(Nv, 8192), got K=%d for %d columns' % (K, Nv))
+def _topk_blocks(blocks, K, Nv):
+    """K best of every row over column blocks handed in one at a time as (first column, (Nt, w) score tensor): each block's K best
+    are taken (laff_topk_rows) and the lists merged by the same kernel -- block lists are laid out in ascending (score, index) order
+    and blocks in column order, so that position order equals index order among equal scores and the reference's tie rule (larger
+    index first) carries over.  A block may be overwritten as soon as the next one is asked for."""
     cap = topk_max_columns(K)
-    if Nv <= cap:
-        return _topk_call(S, K)
     vals, idxs = [], []
-    for c0 in range(0, Nv, cap):
-        blk = S[:, c0:min(Nv, c0 + cap)]
+    for c0, blk in blocks:
         k = min(K, blk.shape[1])
         i, v = _topk_call(blk, k)
         vals.append(v.flip(1))
         idxs.append((i + c0).flip(1))
+    if len(vals) == 1 and vals[0].shape[1] == K:
+        return idxs[0].flip(1).contiguous(), vals[0].flip(1).contiguous()
     cand_v, cand_i = torch.cat(vals, dim=1).contiguous(), torch.cat(idxs, dim=1).contiguous()
     while cand_v.shape[1] > cap:             # very wide collections: merge groups of block lists first
         group = max(2, cap // K) * K
@@ -719,6 +727,52 @@ def topk_rows(S, K):
         cand_v, cand_i = torch.cat(nv, dim=1).contiguous(), torch.cat(ni, dim=1).contiguous()
     pos, val = _topk_call(cand_v, K)
     return torch.gather(cand_i, 1, pos.long()).contiguous(), val
+
+
+def topk_rows(S, K):
+    """Per row: indices (int32) and scores (fp32) of the K best columns, score descending, ties by larger index first (what the
+    reference's `np.argsort(...)[::-1][:K]` yields with a stable sort, predictor.py:53-65).  Any number of columns: a collection that
+    does not fit the kernel's LDS-resident row (~36k columns at K <= 2048) is split into column blocks (_topk_blocks).  K <= 8192."""
+    S, lds = _rows(S, 'S')
+    Nt, Nv = S.shape
+    K = int(K)
+    if K < 1 or K > Nv or K > 8192:
+        raise ValueError('topk_rows: need 1 <= K <= min(Nv, 8192), got K=%d for %d columns' % (K, Nv))
+    cap = topk_max_columns(K)
+    if Nv <= cap:
+        return _topk_call(S, K)
+    return _topk_blocks(((c0, S[:, c0:min(Nv, c0 + cap)]) for c0 in range(0, Nv, cap)), K, Nv)
+
+
+def topk_from_operands(T, V, K, heads=1, block_rows=None, scratch_bytes=192 << 20):
+    """The K best videos of every text WITHOUT the (Nt, Nv) score matrix (the reference argsorts all of it to keep 500-2000 columns
+    per row, predictor.py:53-65; at 100k x 30k that matrix is 12 GB written and read back).  Rows are independent, so the texts are
+    taken in blocks: one block of the text operand is scored against all videos into ONE reusable (block_rows, Nv) buffer
+    (laff_sim_gemm) and reduced to its lists right away (laff_topk_rows; collections wider than its LDS row are split by columns and
+    merged, see topk_rows).  The default buffer (192 MB) stays inside the 256 MB Infinity Cache: the top-K kernel reads the block
+    the GEMM just wrote without going to HBM.  (A running top-K inside the GEMM epilogue is not possible at these K: 64 rows x 2000
+    entries x 8 bytes per wavefront against 160 KB of LDS per CU.)  Scores and order are exactly those of
+    topk_rows(sim_gemm(T, V), K): an entry of the GEMM does not depend on the block it is computed in.
+    Returns (idx int32 (Nt, K), val fp32 (Nt, K))."""
+    if T.precision != V.precision or T.K != V.K:
+        raise ValueError('operands differ in precision or K')
+    Nt, Nv, K = T.N, V.N, int(K)
+    if K < 1 or K > Nv or K > 8192:
+        raise ValueError('topk_from_operands: need 1 <= K <= min(Nv, 8192), got K=%d for %d columns' % (K, Nv))
+    dev = T.buf.device
+    pitch = (Nv + 31) & ~31
+    if block_rows is None:
+        block_rows = max(256, (scratch_bytes // (4 * pitch)) & ~255)
+    block_rows = int(min(max(int(block_rows), 1), Nt))
+    buf = torch.empty((block_rows, pitch), device=dev, dtype=torch.float32)
+    idx = torch.empty((Nt, K), device=dev, dtype=torch.int32)
+    val = torch.empty((Nt, K), device=dev, dtype=torch.float32)
+    for r0 in range(0, Nt, block_rows):
+        r1 = min(Nt, r0 + block_rows)
+        S = sim_gemm(T.rows(r0, r1), V, heads, out=buf[:r1 - r0, :Nv])
+        i, v = topk_rows(S, K)
+        idx[r0:r1], val[r0:r1] = i, v
+    return idx, val
 
 
 def v2t_count(S, grp_off, grp_idx, max_group):

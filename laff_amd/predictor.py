@@ -91,26 +91,33 @@ def retrieval_metrics(S, txt_ids, vis_ids, state=None):
     return t2v_metrics(S, owner), v2t_metrics(S, owner)
 
 
-def topk_lists(S, vis_ids, Threshold=2000):
+def topk_lists(S, vis_ids, Threshold=2000, block_rows=None):
     """(idx (Nt,K) int32, val (Nt,K) float32) numpy: the ranked lists the reference's writers keep per query
     (predictor.py:55-65): the best `Threshold` videos when the collection has at least that many, else -- faithfully to
-    the reference's `inds[index][::-1][0:-1]` -- all but the last one.  Selected and sorted on the device."""
-    if not isinstance(S, torch.Tensor):
+    the reference's `inds[index][::-1][0:-1]` -- all but the last one.  Selected and sorted on the device.
+    S: the (Nt, Nv) score matrix, or `(T, V, heads)` -- the packed GEMM operands (ops.pack_rows) -- in which case the matrix is
+    never materialised (ops.topk_from_operands: blocks of texts scored and reduced one after the other)."""
+    from_ops = isinstance(S, tuple) and len(S) == 3 and isinstance(S[0], ops.Packed)
+    if not from_ops and not isinstance(S, torch.Tensor):
         S = torch.as_tensor(np.ascontiguousarray(S, dtype=np.float32), device='cuda')
     Nv = len(vis_ids)
+    Nt = S[0].N if from_ops else S.shape[0]
     K = Threshold if Nv >= Threshold else Nv - 1
     if K < 1:
-        return np.zeros((S.shape[0], 0), np.int32), np.zeros((S.shape[0], 0), np.float32)
-    idx, val = ops.topk_rows(S, K)
+        return np.zeros((Nt, 0), np.int32), np.zeros((Nt, 0), np.float32)
+    if from_ops:
+        idx, val = ops.topk_from_operands(S[0], S[1], K, heads=S[2], block_rows=block_rows)
+    else:
+        idx, val = ops.topk_rows(S, K)
     return idx.cpu().numpy(), val.cpu().numpy()
 
 
-def txt2video_write_to_file(pred_result_file, S, vis_ids, txt_ids, pkl_saved_file=None, txt_loader=None, Threshold=2000):
+def txt2video_write_to_file(pred_result_file, S, vis_ids, txt_ids, pkl_saved_file=None, txt_loader=None, Threshold=2000, block_rows=None):
     """predictor.txt2video_write_to_file (predictor.py:53-88) fed by the device top-K instead of a full-matrix argsort:
     `id.sent.score.txt` lines `txt_id vis_id score vis_id score ...` (scores printed as numpy float32, like the
     reference) and the `t2v.pkl` dict {txt_id: {query, rank_list, sim_value}}."""
     import pickle
-    idx, val = topk_lists(S, vis_ids, Threshold)
+    idx, val = topk_lists(S, vis_ids, Threshold, block_rows)       # (S may be the packed operands (T, V, heads): no score matrix)
     vis = np.asarray(vis_ids, dtype=object)
     shot_dict = {}
     fout = open(pred_result_file, 'w') if pred_result_file is not None else None

@@ -471,3 +471,41 @@ def test_c4_40k_x_10k_oracle_sampled():
 
 def test_c5_laff_ml_oracle_sampled():
     _oracle_sampled_parity('c5_ml_100kx30k', 'bf16', 500)
+
+
+def test_c5_sized_top2000_without_the_score_matrix():
+    """100,000 texts x 30,000 videos x 8 heads of 512 (BASELINE config C5), the reference writer's Threshold = 2000 lists straight
+    from the bf16 operands: the 12 GB score matrix is never allocated (peak extra device memory < 3 GB: 0.2 GB block buffer + the
+    1.6 GB of lists + top-K scratch), and sampled rows equal the lists taken from their materialised score rows."""
+    from laff_amd import ops
+    Nt, Nv, H, d, K = 100000, 30000, 8, 512, 2000
+    g = torch.Generator(device=DEV).manual_seed(9)
+    z = torch.randn(Nv, 64, generator=g, device=DEV)
+    P = torch.randn(64, H * d, generator=g, device=DEV) * 0.3
+    own = torch.randint(0, Nv, (Nt,), generator=g, device=DEV)
+    Ev = (z @ P + torch.randn(Nv, H * d, generator=g, device=DEV)).reshape(Nv, H, d)
+    V = ops.pack_rows(Ev, True, 1e-13, 'bf16')
+    del Ev
+    T_parts = []
+    Tbuf = torch.empty((Nt * H * d * 2,), device=DEV, dtype=torch.uint8)
+    for a in range(0, Nt, 20000):
+        Et = (z[own[a:a + 20000]] @ P + torch.randn(20000, H * d, generator=g, device=DEV)).reshape(20000, H, d)
+        part = ops.pack_rows(Et, True, 1e-13, 'bf16')
+        Tbuf[a * H * d * 2:(a + 20000) * H * d * 2] = part.buf[:20000 * H * d * 2]
+        del Et, part
+    T = ops.Packed(Tbuf, Nt, H * d, 'bf16', 1.0)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    idx, val = ops.topk_from_operands(T, V, K, heads=H)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < 3 * (1 << 30), peak
+    assert idx.shape == (Nt, K) and bool((val[:, :-1] >= val[:, 1:]).all())
+    rows = torch.arange(0, Nt, 997, device=DEV)
+    for r in rows[:40].tolist():
+        S = ops.sim_gemm(T.rows(r, r + 1), V, H)
+        i0, v0 = ops.topk_rows(S, K)
+        assert torch.equal(i0[0], idx[r]) and torch.equal(v0[0], val[r])
+    # the owner video is (nearly always) the first entry
+    assert float((idx[:, 0].long() == own).float().mean()) > 0.9

@@ -415,6 +415,46 @@ def test_result_writers_golden(golden, tmp_path):
             assert [repr(float(x)) for x in got[k]['sim_value']] == exp[k]['sim_value']
 
 
+def test_result_writers_from_operands_golden(golden, tmp_path):
+    """The same two files WITHOUT a score matrix: the writer is handed packed GEMM operands (here T = the fixture's score rows and
+    V = the identity, fp32: T.V^T reproduces the fixture's scores exactly) and takes the lists from ops.topk_from_operands, blocks
+    of 7 texts at a time."""
+    from laff_amd import ops, predictor
+    g = golden('writers')
+    S, vis_ids, txt_ids = g['S'], g.json('vis_ids'), g.json('txt_ids')
+    Nt, Nv = S.shape
+    Kp = (Nv + 15) & ~15
+    t = np.zeros((Nt, Kp), np.float32); t[:, :Nv] = S
+    v = np.zeros((Nv, Kp), np.float32); v[np.arange(Nv), np.arange(Nv)] = 1.0
+    T, V = ops.pack_rows(dev(t), False, 1e-13, 'fp32'), ops.pack_rows(dev(v), False, 1e-13, 'fp32')
+    assert torch.equal(ops.sim_gemm(T, V), dev(S))
+    for name, thr in (('top10', 10), ('all', 2000)):
+        f = str(tmp_path / (name + '.txt'))
+        predictor.txt2video_write_to_file(f, (T, V, 1), vis_ids, txt_ids, Threshold=thr, block_rows=7)
+        assert open(f).read() == str(g[name + '/text'])
+
+
+@pytest.mark.parametrize('prec', ['fp16', 'fp16x3'])
+def test_topk_from_operands_equals_topk_of_the_score_matrix(prec):
+    """Row-blocked top-K straight from the operands == top-K of the materialised matrix, indices and scores, with exact ties
+    (duplicated videos) inside and across the kept part."""
+    from laff_amd import ops
+    g = rnd(5)
+    Nt, Nv, K = 1500, 2600, 512
+    v = g.normal(0, 1, (Nv, K)).astype(np.float32)
+    v[1300:1500] = v[100:300]                          # 200 exact duplicates: equal scores, larger index first
+    t = (v[g.integers(0, Nv, Nt)] + 0.7 * g.normal(0, 1, (Nt, K))).astype(np.float32)
+    T, V = ops.pack_rows(dev(t), True, 1e-13, prec), ops.pack_rows(dev(v), True, 1e-13, prec)
+    S = ops.sim_gemm(T, V)
+    for k in (1, 37, 700):
+        i0, v0 = ops.topk_rows(S, k)
+        i1, v1 = ops.topk_from_operands(T, V, k, block_rows=400)
+        assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    i2, v2 = ops.topk_from_operands(T, V, 37)           # default block: one pass
+    i0, v0 = ops.topk_rows(S, 37)
+    assert torch.equal(i0, i2) and torch.equal(v0, v2)
+
+
 # ---------------------------------------------------------------------------------------------- a1, sparse input (bow)
 def _random_csr(g, N, Dk, max_nnz):
     rows = []
