@@ -409,7 +409,8 @@ def main():
                 graph = graphs[0]
                 if args.two_streams:
                     # steps k and k+1 on two streams: the latency-bound tail of a step (prepare / resolve / metrics, the sparse last
-                    # round of a GEMM) runs beside the next step's first kernels; the two captures share nothing but read-only inputs
+                    # round of a GEMM) runs beside the next step's first kernels; the two captures share read-only inputs only (each
+                    # captured laff_rank_metrics_async call has its own device result slot)
                     side = [torch.cuda.Stream(), torch.cuda.Stream()]
         except Exception as e:  # noqa: BLE001
             print('warning: HIP graph capture failed (%s); timing eager launches' % e, file=sys.stderr)

@@ -12,10 +12,14 @@
 
 #include "kernels.h"
 
+constexpr int METRIC_SLOTS = 33;
+
 struct laff_ctx {
     int device;
     hipStream_t stream;
-    double* d_metrics = nullptr;   // 7 doubles + 1 flag (device): 0.0 / 1.0 (a rank < 1 was seen: metrics are NaN)
+    double* d_metrics = nullptr;   // METRIC_SLOTS x (7 doubles + 1 flag: 0.0 / 1.0 = a rank < 1 was seen, metrics are NaN) on the device
+    unsigned metrics_slot = 0;     // every laff_rank_metrics_async call takes the next slot: calls captured into different graphs (or in
+                                   // flight on different streams) do not share their result buffer
     double* h_metrics = nullptr;   // pinned host mirror
 };
 
@@ -713,12 +717,13 @@ int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, int base, i
     if (Nq < 1) return fail(LAFF_E_SHAPE, "laff_rank_metrics_async: Nq=%d", Nq);
     DeviceGuard g(ctx->device);
     if (!ctx->d_metrics) {
-        HIP_TRY(hipMalloc((void**)&ctx->d_metrics, 8 * sizeof(double)));
-        HIP_TRY(hipMemset(ctx->d_metrics, 0, 8 * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&ctx->d_metrics, METRIC_SLOTS * 8 * sizeof(double)));
+        HIP_TRY(hipMemset(ctx->d_metrics, 0, METRIC_SLOTS * 8 * sizeof(double)));
         HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
     }
-    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, ctx->d_metrics + 7, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(out8, ctx->d_metrics, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double* slot = ctx->d_metrics + 8 * (size_t)(1 + ctx->metrics_slot++ % (METRIC_SLOTS - 1));      // (slot 0: the synchronous call)
+    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, slot, slot + 7, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out8, slot, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return LAFF_OK;
 }
 
@@ -728,8 +733,8 @@ int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, int base, int* ra
     if (Nq < 1) return fail(LAFF_E_SHAPE, "laff_rank_metrics: Nq=%d", Nq);
     DeviceGuard g(ctx->device);
     if (!ctx->d_metrics) {
-        HIP_TRY(hipMalloc((void**)&ctx->d_metrics, 8 * sizeof(double)));
-        HIP_TRY(hipMemset(ctx->d_metrics, 0, 8 * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&ctx->d_metrics, METRIC_SLOTS * 8 * sizeof(double)));
+        HIP_TRY(hipMemset(ctx->d_metrics, 0, METRIC_SLOTS * 8 * sizeof(double)));
         HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
     }
     HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, ctx->d_metrics + 7, ctx->stream));
