@@ -441,8 +441,11 @@ def frame_fuse_grouped(frames_list, lens, params, flags):
 
 
 def default_prescale(precision):
-    """fp16 operands are pre-scaled by 64 (exact) so that the low part of the hi/lo split stays normal."""
-    return 64.0 if precision in ('fp16', 'fp16x3') else 1.0
+    """fp16x3 operands are pre-scaled by 64 (exact) so that the low part of the hi/lo split stays normal.  Single-pass fp16 operands
+    are not scaled: the fp16 MFMA honours denormal inputs exactly (tools/debug/denorm_probe.py), an element below 2^-14 of a unit-norm
+    row then carries an absolute error of 2^-25 -- that of its normal neighbours -- and the measured band (laff_rank_prepare) covers
+    it; with scale == 1 the GEMM epilogue has no product per score to make (sim_strip.hip, SCALE1)."""
+    return 64.0 if precision == 'fp16x3' else 1.0
 
 
 class Packed:

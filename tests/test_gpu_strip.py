@@ -62,10 +62,10 @@ def _run(ops, Et, Ev, gt, prec, want_scores, ldo=None, pair_cap=None, prescale=N
     return S, st
 
 
-@pytest.mark.parametrize('prec,prescale', [('fp16', None), ('fp16', 1.0), ('bf16', None)])
+@pytest.mark.parametrize('prec,prescale', [('fp16', None), ('fp16', 64.0), ('bf16', None)])
 def test_strip_equals_tiled_at_c4(strip_mode, prec, prescale):
     """40000 x 10000 (BASELINE config C4): scores bit-identical to the tiled kernel's, same band pairs, counts equal to the float64
-    ranks; prescale 1 is the scale == 1 instantiation (no multiply in the epilogue)."""
+    ranks; the default (no prescale) is the scale == 1 instantiation (no multiply in the epilogue), prescale 64 the general one."""
     from laff_amd import ops
     Et, Ev, gt = _embeddings(40000, 10000, 9.0, 3)
     want = _fp64_count(Et, Ev, gt)
