@@ -61,6 +61,37 @@ def _row_chunks(pending, limit_bytes=1 << 31):
     return out
 
 
+def _loader_len(loader):
+    ds = getattr(loader, 'dataset', None)
+    try:
+        return len(ds) if ds is not None else len(loader)
+    except TypeError:
+        return 1
+
+
+def coalesce_batches(batches):
+    """Concatenate the batch dicts of a loader into one: tensors / arrays along dim 0, lists and tuples end to end, nested dicts
+    key by key, None stays None.  Raises TypeError / ValueError / RuntimeError when the batches do not line up."""
+    if not batches:
+        return None
+    first = batches[0]
+    if isinstance(first, dict):
+        if any(not isinstance(b, dict) or b.keys() != first.keys() for b in batches):
+            raise ValueError('batch dicts with different keys')
+        return {k: coalesce_batches([b[k] for b in batches]) for k in first}
+    if first is None:
+        if any(b is not None for b in batches):
+            raise ValueError('None mixed with values')
+        return None
+    if isinstance(first, torch.Tensor):
+        return torch.cat(list(batches), dim=0)
+    if isinstance(first, np.ndarray):
+        return np.concatenate(list(batches), axis=0)
+    if isinstance(first, (list, tuple)):
+        return [x for b in batches for x in b]
+    raise TypeError('cannot concatenate batch values of type %s' % type(first).__name__)
+
+
 def run_fc(pending):
     """Launch every queued FC projection as one grouped GEMM."""
     if FC_PRECISION == 'fp16x3':
@@ -629,13 +660,27 @@ class W2VVPP(nn.Module):
     #: (1.6 GB over PCIe at C4 is 40x the GEMM), so it takes the split-product GEMM whose scores are fp32-class (~2e-7) like the
     #: reference's own; bench.py / retrieval.evaluate choose their precision themselves
     predict_precision = 'fp16x3'
+    #: retrieve() / predict() run each tower ONCE over all loader batches (False: one launch set per batch, like the reference's loop)
+    coalesce_loader_batches = True
 
     def _embed_whole(self, vis_loader, txt_loader):
-        """Both towers once over the whole matrices of loaders that can hand them over (`whole()`: laff_amd.data.Bulk*Loader):
-        every FC projection of both towers in ONE grouped launch, one fuse launch per side -- instead of one launch set per
-        loader batch (780 of them at C4 with the shipped batch size of 64, shell/retrieval_task.sh:161).  Row-wise arithmetic, so the
-        embeddings are bit-identical to the per-batch route on tiles of the same kind."""
-        out, (cap, _, txt_ids) = vis_loader.whole(), txt_loader.whole()
+        """Both towers once over the whole matrices: every FC projection of both towers in ONE grouped launch, one fuse launch per
+        side -- instead of one launch set per loader batch (780 of them at C4 with the shipped batch size of 64,
+        shell/retrieval_task.sh:161).  Loaders that can hand the matrices over do (`whole()`: laff_amd.data.Bulk*Loader); the batches of
+        any other loader -- the reference's own DataLoaders -- are collected and concatenated first (`coalesce_batches`).  Row-wise
+        arithmetic, so the embeddings are bit-identical to the per-batch route on tiles of the same kind.  Returns None when the
+        batches cannot be concatenated (frame tensors padded to different lengths, foreign value types): per-batch route."""
+        if hasattr(vis_loader, 'whole') and hasattr(txt_loader, 'whole'):
+            out, (cap, _, txt_ids) = vis_loader.whole(), txt_loader.whole()
+        else:
+            try:
+                out = coalesce_batches(list(vis_loader))
+                tb = list(txt_loader)
+                cap, txt_ids = coalesce_batches([b[0] for b in tb]), [i for b in tb for i in b[2]]
+            except (TypeError, ValueError, RuntimeError):
+                return None
+            if out is None or cap is None:
+                return None
         pending = []
         fin_v = self.vis_net.prepare(out['vis_feat_dict'], out.get('vis_frame_feat_dict', {}), pending)
         fin_t = self.txt_net.prepare(cap, pending)
@@ -658,10 +703,12 @@ class W2VVPP(nn.Module):
             self.video_idxs_list = []
         precision = precision or self.sim_precision or self.predict_precision
         with torch.no_grad():
-            whole = (hasattr(vis_loader, 'whole') and hasattr(txt_loader, 'whole') and len(vis_loader.dataset) > 0 and
-                     len(txt_loader.dataset) > 0 and (not record_emb or self.video_all_embs is None))
-            if whole:
-                self.video_all_embs, self.video_idxs_list, self.vis_ids, txt_all, txt_ids = self._embed_whole(vis_loader, txt_loader)
+            whole = None
+            if (self.coalesce_loader_batches and (not record_emb or self.video_all_embs is None) and
+                    _loader_len(vis_loader) > 0 and _loader_len(txt_loader) > 0):
+                whole = self._embed_whole(vis_loader, txt_loader)
+            if whole is not None:
+                self.video_all_embs, self.video_idxs_list, self.vis_ids, txt_all, txt_ids = whole
             else:
                 if not record_emb or self.video_all_embs is None:
                     self.video_all_embs, self.video_idxs_list, self.vis_ids = self._embed_videos(vis_loader)

@@ -193,6 +193,16 @@ def test_predict_golden(golden):
     np.testing.assert_allclose(v2t16e, g['v2t_metrics'], rtol=0, atol=1e-9)
     heads, _, _ = model.predict_each_head(tl, vl, 'cosine')
     assert maxdiff(heads.mean(axis=0), g['scores']) <= 1e-4
+    # the batches of a plain loader are coalesced into one launch set per tower; the per-batch route gives the same triple
+    model.sim_precision = 'fp16x3'
+    model.coalesce_loader_batches = False
+    try:
+        sb, tb, vb = model.predict(tl, vl, 'cosine')
+    finally:
+        model.coalesce_loader_batches = True
+    sw, tw, vw = model.predict(tl, vl, 'cosine')
+    assert list(tb) == list(tw) and list(vb) == list(vw)
+    assert maxdiff(sb, sw) <= 2e-6 and maxdiff(sw, g['scores']) <= 5e-6
 
 
 def test_single_head_model_runs_2d():
