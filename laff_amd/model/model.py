@@ -766,7 +766,29 @@ class W2VVPP(nn.Module):
         """Same contract as the reference (model/model.py:1018-1079): (np.float32[Nt,Nv] in loader row order,
         txt_ids, vis_ids).  Embeddings stay in HBM, all pairs are scored by one GEMM, one D2H copy at the end."""
         S, txt_ids, vis_ids = self.retrieve(txt_loader, vis_loader, measure, record_emb)
-        return S.cpu().numpy(), txt_ids, vis_ids
+        return self._scores_to_host(S), txt_ids, vis_ids
+
+    def _scores_to_host(self, S):
+        """The score matrix as a numpy array: one asynchronous copy into a PINNED host buffer -- 1.6 GB at C4 take ~30 ms that way
+        against ~200 ms through pageable memory.  The array owns that buffer; the buffer is taken again by the next call only once the
+        caller has dropped the array (weak reference), so results never alias."""
+        if not S.is_cuda or S.numel() < (1 << 20):
+            return S.cpu().numpy()
+        import weakref
+        buf, ref = getattr(self, '_pinned_scores', None), getattr(self, '_pinned_scores_user', None)
+        if buf is None or buf.numel() < S.numel() or (ref is not None and ref() is not None):
+            self._pinned_scores = self._pinned_scores_user = None
+            try:
+                buf = torch.empty((S.numel(),), dtype=S.dtype, pin_memory=True)
+            except RuntimeError:
+                return S.cpu().numpy()
+            self._pinned_scores = buf
+        host = buf[:S.numel()].view(S.shape)
+        host.copy_(S, non_blocking=True)
+        torch.cuda.current_stream(S.device).synchronize()
+        out = host.numpy()
+        self._pinned_scores_user = weakref.ref(out)
+        return out
 
     def predict_batch(self, txt_loader, vis_loader, measure, record_emb=False):
         """The reference switches to a re-embedding loop above 5e4 videos to bound host memory (:1081-1128);
