@@ -60,8 +60,10 @@ constexpr int SLAB_OFF = RING * STAGE;         // per-wave fp32 transpose slabs,
 constexpr int SLAB_JOB = 32 * 128;             // 128-byte rows, 16-byte chunk c of row r at position c ^ ((r >> 1) & 3) -- conflict-free for
 constexpr int SLAB_BYTES = 2 * SLAB_JOB;       // the quad-column ds_write_b128 (8 rows at a time) and the row-wise ds_read_b128 (a row per 8 lanes)
 constexpr int BAND_OFF = SLAB_OFF + 4 * SLAB_BYTES;       // band maximum of every aligned group of 64 columns (fp32)
-constexpr int SMEM = BAND_OFF + STRIP_MAX_GROUPS * 4;
-static_assert(SMEM <= 160 * 1024 && CB == 32, "LDS budget / block width");
+constexpr int DUMP_OFF = BAND_OFF + STRIP_MAX_GROUPS * 4;  // per-wave staging of one chunk of dumped groups (STRIP_CHUNK entries)
+constexpr int DUMP_BYTES = STRIP_CHUNK * STRIP_ENTRY_WORDS * 4;
+constexpr int SMEM = DUMP_OFF + 4 * DUMP_BYTES;
+static_assert(SMEM <= 160 * 1024 && CB == 32 && DUMP_BYTES % 1024 == 0, "LDS budget / block width / whole-wave flush passes");
 
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -210,7 +212,7 @@ constexpr EpiStream make_epi_stream() {
                 if (job > 0 && (e & 3) == 3) { push(OP_WAITR, 0, e >> 2); push(OP_STG, 0, e >> 2); }
             }
         }
-        if (BANDED) { push(OP_MIN, job, 15); push(OP_CHK, job, 0); push(OP_CNT, job, 0); }
+        if (BANDED) { push(OP_MIN, job, 15); if (job == 1) push(OP_CHK, 1, 0); push(OP_CNT, job, 0); }
         if (HAVE_S) for (int i = 0; i < 4; ++i) push(OP_DSR, job, i);
     }
     if (HAVE_S)
@@ -370,6 +372,20 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
         float* dst = (float*)(smem + BAND_OFF);
         for (int i = tid; i < (nC + 63) / 64; i += 256) dst[i] = bm[i];
     }
+    // a staged chunk of dumped groups -> the list (see dump_group)
+    const unsigned dump_base = lds0 + DUMP_OFF + (unsigned)wave * DUMP_BYTES;
+    auto flush_chunk = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the staged entries are written
+        const unsigned cbase = cur_chunk < NCH ? list_base + cur_chunk * (unsigned)DUMP_BYTES : 0x80000000u;     // (no chunk: dropped by the bounds check)
+        unsigned lane16 = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(lane16));
+#pragma unroll 1
+        for (unsigned k = 0; k < (unsigned)DUMP_BYTES; k += 1024u) {
+            u32x4 t;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(dump_base + lane16 + k) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(t), "v"(cbase + lane16 + k), "s"(rsrcP) : "memory");
+        }
+    };
     __syncthreads();
     STAMP(1);
     const unsigned long long vbytes = (unsigned long long)(unsigned)nC * (unsigned)KBYTES;     // the video operand: 1,024-byte rows
@@ -446,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
         // Initial value: nothing counted, nothing listed -- the first body's epilogue runs on an all-zero accumulator set.
         float thr_lo[2] = {__builtin_inff(), __builtin_inff()}, thr_hi[2] = {__builtin_inff(), __builtin_inff()};
         // epilogue state
-        unsigned sh[4] = {0, 0, 0, 0}, mm = 0;
+        unsigned sh[4] = {0, 0, 0, 0}, mmj[2] = {0, 0};
         float tt[4] = {0, 0, 0, 0};
         u32x4 rr[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         u32x4 rsrcSb = {0, 0, 0, 0x00020000u};      // the score rows of the block whose epilogue is running
@@ -493,14 +509,17 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
         });
 
         // ---- one dumped group: 16 raw accumulators of one lane + what laff_rank_resolve needs to test them {row, colbase, lo, hi |
-        // mask16, the row's ground-truth column, 0, 0 | x[16]}.  Six 16-byte buffer stores, four of them straight from the accumulator
-        // registers (32-bit offsets into the list; the descriptor's bounds check drops what does not fit).
+        // mask16, the row's ground-truth column, 0, 0 | x[16]}.  The groups are staged in LDS, a chunk (STRIP_CHUNK entries) per
+        // wavefront, and a full chunk leaves with six whole-wave 16-byte stores: as six global stores per dumped lane the
+        // entries sat in the wave's in-order memory queue, where the counted vmcnt waits of the block barrier had to wait for them
+        // too -- a store round trip per dump, and a third of the jobs dump (0.03 ms of 0.36 at C4).  LDS writes retire in ~100 cycles.
         auto dump_group = [&](bool hit, int row, int colbase, float lo, float hi, unsigned mask16, int gt_col_of_row, const f32x16& x) {
             const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
             if (m == 0ull) return;
             const unsigned n = (unsigned)__builtin_popcountll(m);
             if (cur_n + n > STRIP_CHUNK) {                                   // wave-uniform, once per STRIP_CHUNK entries at most
                 gu32* pp = (gu32*)pPairs;
+                flush_chunk();
                 if (lane == 0 && cur_chunk < NCH) pp[4 + cur_chunk] = cur_n;  // close the chunk
                 unsigned nc = 0;
                 if (lane == 0) nc = NW + __hip_atomic_fetch_add(pp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -509,23 +528,24 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                 if (lane == 0 && cur_chunk >= NCH) pp[1] = 1u;                // pool exhausted: flagged, the entries are dropped
             }
             const unsigned slot = cur_n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            const unsigned cbase = cur_chunk < NCH ? list_base + cur_chunk * (STRIP_CHUNK * STRIP_ENTRY_WORDS * 4u) : 0x80000000u;
             cur_n += n;
+#ifdef LAFF_STRIP_NODUMPBODY
+            if (false) {
+#else
             if (hit) {
-                const unsigned voff = cbase + slot * (STRIP_ENTRY_WORDS * 4u);
+#endif
+                const unsigned at = dump_base + slot * (STRIP_ENTRY_WORDS * 4u);
                 const f32x4 q0 = {x[0], x[1], x[2], x[3]}, q1 = {x[4], x[5], x[6], x[7]}, q2 = {x[8], x[9], x[10], x[11]},
                             q3 = {x[12], x[13], x[14], x[15]};
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:32" ::"v"(q0), "v"(voff), "s"(rsrcP) : "memory");
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:48" ::"v"(q1), "v"(voff), "s"(rsrcP) : "memory");
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:64" ::"v"(q2), "v"(voff), "s"(rsrcP) : "memory");
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:80" ::"v"(q3), "v"(voff), "s"(rsrcP) : "memory");
+                lds_write128<32>(at, q0);
+                lds_write128<48>(at, q1);
+                lds_write128<64>(at, q2);
+                lds_write128<80>(at, q3);
                 u32x4 h, h2;
                 h.x = (unsigned)row; h.y = (unsigned)colbase; h.z = __float_as_uint(lo); h.w = __float_as_uint(hi);
                 h2.x = mask16; h2.y = (unsigned)gt_col_of_row; h2.z = 0u; h2.w = 0u;
-                // (s_nop behind the header stores: hipcc does not know these are stores, and a 16-byte store reads its data registers
-                // for a few cycles after issue -- the temporaries may be handed to the very next instruction)
-                asm volatile("buffer_store_dwordx4 %0, %1, %3, 0 offen\n\tbuffer_store_dwordx4 %2, %1, %3, 0 offen offset:16\n\ts_nop 1"
-                             ::"v"(h), "v"(voff), "v"(h2), "s"(rsrcP) : "memory");
+                // (s_nop behind the header writes: hipcc does not know these are stores, the temporaries may be handed to the next instruction)
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\ts_nop 1" ::"v"(at), "v"(h), "v"(h2) : "memory");
             }
         };
 
@@ -631,8 +651,8 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
             } else if constexpr (op.kind == OP_MIN) {
                 // pair (arg - 1, arg).  Statements that share a register sit at least two statements apart (hipcc puts an s_nop between
                 // closer ones): four rotating t registers and sign-bit shift registers, the minimum two elements behind.
-                if constexpr (arg == 1) asm volatile("v_min_u32 %0, %1, %2" : "=v"(mm) : "v"(tt[0]), "v"(tt[1]));
-                else asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(mm) : "v"(tt[(arg - 1) & 3]), "v"(tt[arg & 3]));
+                if constexpr (arg == 1) asm volatile("v_min_u32 %0, %1, %2" : "=v"(mmj[rb]) : "v"(tt[0]), "v"(tt[1]));
+                else asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(mmj[rb]) : "v"(tt[(arg - 1) & 3]), "v"(tt[arg & 3]));
             } else if constexpr (op.kind == OP_DSW) {
                 // quad `arg` of the job (accumulators 4 arg .. 4 arg + 3) times scale -> the slab, one asm statement: products in a scratch
                 // quad (two in turn: the LDS store is still reading its data registers when the next quad's first product is issued
@@ -660,16 +680,19 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                 }
 #endif
             } else if constexpr (op.kind == OP_CHK) {
-                // in the band <=> 0 <= t <= hi - lo; the test here may only be WIDER than the band (laff_rank_resolve applies the exact
-                // one to what is dumped).  Rows beyond the matrix have lo = hi = inf: w is NaN, nothing passes.
-                const float w = (thr_hi[rb] - thr_lo[rb]) * 1.000002f + 1e-30f;
-                const bool hit = w >= 0.0f && mm <= __float_as_uint(w);           // (mm: unsigned minimum of the bits of the job's 16 t values)
+                // ONE test per block for both jobs (a ballot + scalar branch costs a lone wave ~60 cycles: 4 % of the launch as one per
+                // job).  In the band <=> 0 <= t <= hi - lo; the test here may only be WIDER than the band (laff_rank_resolve applies the
+                // exact one to what is dumped).  Rows beyond the matrix have lo = hi = inf: w is NaN, nothing passes.
+                const float w0 = (thr_hi[0] - thr_lo[0]) * 1.000002f + 1e-30f, w1 = (thr_hi[1] - thr_lo[1]) * 1.000002f + 1e-30f;
+                // (mmj: unsigned minimum of the bits of the job's 16 t values)
+                const bool hit0 = w0 >= 0.0f && mmj[0] <= __float_as_uint(w0), hit1 = w1 >= 0.0f && mmj[1] <= __float_as_uint(w1);
 #ifdef LAFF_STRIP_NOCHK
                 if (false) {
 #else
-                if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {                      // a third of the jobs at C4 (fp16 operands)
+                if (__builtin_amdgcn_ballot_w64(hit0 || hit1) != 0ull) {             // half of the blocks at C4 (fp16 operands)
 #endif
-                    dump_group(hit, row_w + rb * 32 + l31, cbp * CB + 4 * hh, thr_lo[rb], thr_hi[rb], 0xffffu, gtc[rb], acc[Q][rb]);
+                    dump_group(hit0, row_w + l31, cbp * CB + 4 * hh, thr_lo[0], thr_hi[0], 0xffffu, gtc[0], acc[Q][0]);
+                    dump_group(hit1, row_w + 32 + l31, cbp * CB + 4 * hh, thr_lo[1], thr_hi[1], 0xffffu, gtc[1], acc[Q][1]);
                 }
             } else if constexpr (op.kind == OP_CNT) {
                 cnt[rb] += __builtin_popcount(sh[0]) + __builtin_popcount(sh[1]) + __builtin_popcount(sh[2]) + __builtin_popcount(sh[3]);
@@ -832,6 +855,7 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
     }
     m0_set(m0_keep);
     if constexpr (BANDED) {
+        if (cur_n) flush_chunk();
         if (lane == 0 && cur_chunk < NCH) ((gu32*)pPairs)[4 + cur_chunk] = cur_n;        // close this wave's last chunk
     }
 #undef STAMP
@@ -851,6 +875,7 @@ bool sim_strip_eligible(const GemmArgs& a, int mode, bool aligned) {
     if (a.s_gt && !a.s_gt64) return false;                               // the legacy approximate count stays on the tiled kernel
     if (a.count && !a.s_gt64) return false;
     if (a.out && ((a.ldo & 3) || (((uintptr_t)a.out) & 15))) return false;
+    if (a.out && (long)SR * a.ldo * 4 >= (1ll << 32)) return false;     // the score rows of a strip are addressed through one raw buffer
     if ((long)a.nC * KBYTES >= (1ll << 32) || (a.nC + 63) / 64 > STRIP_MAX_GROUPS) return false;
     if (a.pairs && (16ull + 8ull * a.pair_cap) >= (1ull << 32)) return false;
     const long units = (long)((a.nR + SR - 1) / SR) * ((a.nC + CB - 1) / CB);
