@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 12
+#define LAFF_ABI_VERSION 13
 
 enum {
     LAFF_OK = 0,
@@ -309,6 +309,23 @@ int laff_rank_metrics(laff_ctx* ctx, const int* r, int Nq, int base, int* ranks_
 /* Same, without synchronising: out8 is PINNED HOST memory (8 doubles: the 7 metrics + an error flag, 1.0 if a rank < 1 was
  * seen -- the 7 metrics are then NaN -- else 0.0); valid once the stream has been synchronised.  Capturable in a HIP graph. */
 int laff_rank_metrics_async(laff_ctx* ctx, const int* r, int Nq, int base, int* ranks_out, double* out8_pinned_host);
+
+/* ---- e: the collectives of the sharded path for a host that is not Python (laff_amd/dist.py issues the same three through
+ * torch.distributed).  One process per GPU; RCCL is looked up at the first call (a copy already loaded into
+ * the process first, then librccl.so / librccl.so.1) -- the library does not link against it, LAFF_E_UNSUPPORTED when there is none.
+ * Every call is asynchronous on the stream the comm was created with (the ctx's; laff_comm_set_stream re-binds it).
+ *   'video' scheme (the reference's loop model/model.py:1057-1077 sharded by video rows): laff_allgather_rows on the text
+ *   embeddings, laff_allreduce_f64_max on s_gt64 (laff_rank_prepare writes -inf for texts whose video lives elsewhere),
+ *   laff_allreduce_i32_sum on the counts (the overflow poison -2^26 survives a sum over up to 16 shards). */
+#define LAFF_COMM_ID_BYTES 128
+typedef struct laff_comm laff_comm;
+int laff_comm_unique_id(unsigned char* id /*[LAFF_COMM_ID_BYTES], made by one rank, handed to the others out of band*/);
+int laff_comm_init(laff_ctx* ctx, int rank, int world, const unsigned char* id, laff_comm** out);
+int laff_comm_set_stream(laff_comm* comm, void* hip_stream);
+int laff_comm_destroy(laff_comm* comm);
+int laff_allgather_rows(laff_comm* comm, const void* send, void* recv, size_t bytes_per_rank);     /* recv: world x bytes, rank order */
+int laff_allreduce_i32_sum(laff_comm* comm, int* buf, size_t n);                                    /* in place */
+int laff_allreduce_f64_max(laff_comm* comm, double* buf, size_t n);                                 /* in place */
 
 #ifdef __cplusplus
 }

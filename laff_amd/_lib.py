@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get('LAFF_HIP_LIB') or os.path.join(_HERE, 'lib', 'liblaff
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class Plane(C.Structure):
@@ -74,6 +74,13 @@ SIGNATURES = {
     'laff_rank_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _I]),
     'laff_topk_rows': (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
     'laff_v2t_count': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    'laff_comm_unique_id': (C.c_int, [_P]),
+    'laff_comm_init': (C.c_int, [_P, _I, _I, _P, C.POINTER(_P)]),
+    'laff_comm_set_stream': (C.c_int, [_P, _P]),
+    'laff_comm_destroy': (C.c_int, [_P]),
+    'laff_allgather_rows': (C.c_int, [_P, _P, _P, C.c_size_t]),
+    'laff_allreduce_i32_sum': (C.c_int, [_P, _P, C.c_size_t]),
+    'laff_allreduce_f64_max': (C.c_int, [_P, _P, C.c_size_t]),
     'laff_v2t_count_exact': (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, C.c_uint]),
     'laff_rank_metrics': (C.c_int, [_P, _P, _I, _I, _P, C.POINTER(C.c_double)]),
     'laff_rank_metrics_async': (C.c_int, [_P, _P, _I, _I, _P, _P]),

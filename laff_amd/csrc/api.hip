@@ -96,6 +96,15 @@ int laff_ctx_create(int device, void* hip_stream, laff_ctx** out) {
     return LAFF_OK;
 }
 
+/* internal (comm.hip): the ctx's stream and device; the error text of the calling thread */
+int laff_ctx_stream_device(laff_ctx* ctx, void** stream, int* device) {
+    CHECK_CTX(ctx);
+    *stream = (void*)ctx->stream;
+    *device = ctx->device;
+    return LAFF_OK;
+}
+void laff_set_error(const char* msg) { g_err = msg ? msg : ""; }
+
 int laff_ctx_set_stream(laff_ctx* ctx, void* hip_stream) {
     CHECK_CTX(ctx);
     ctx->stream = static_cast<hipStream_t>(hip_stream);

@@ -800,3 +800,33 @@ def test_exact_ranks_shard_semantics_and_overflow_flag():
     assert 0 < n <= 8 and overflow          # (n: the pairs that fitted)
     with pytest.raises(RuntimeError, match='rank < 1'):
         ops.rank_metrics(st.count, base=1)
+
+
+def test_c_abi_collectives_on_a_one_rank_group():
+    """laff_comm_* / laff_allgather_rows / laff_allreduce_* (include/laff_hip.h, section e) on a 1-rank RCCL communicator: RCCL is found at
+    run time, the calls run on torch's stream, and with one rank every collective is the identity."""
+    import ctypes as C
+    from laff_amd import _lib, ops
+    lib, h = ops._context(torch.device(DEV))
+    uid = (C.c_ubyte * 128)()
+    _lib.check(lib.laff_comm_unique_id(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.laff_comm_init(h, 0, 1, uid, C.byref(comm)))
+    try:
+        _lib.check(lib.laff_comm_set_stream(comm, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        g = torch.Generator(device=DEV).manual_seed(1)
+        rows = torch.randn(300, 512, generator=g, device=DEV)
+        out = torch.empty_like(rows)
+        _lib.check(lib.laff_allgather_rows(comm, C.c_void_p(rows.data_ptr()), C.c_void_p(out.data_ptr()), rows.numel() * 4))
+        cnt = torch.arange(-5, 995, device=DEV, dtype=torch.int32)
+        cnt0 = cnt.clone()
+        _lib.check(lib.laff_allreduce_i32_sum(comm, C.c_void_p(cnt.data_ptr()), cnt.numel()))
+        sg = torch.randn(1000, generator=g, device=DEV, dtype=torch.float64)
+        sg[::7] = float('-inf')
+        sg0 = sg.clone()
+        _lib.check(lib.laff_allreduce_f64_max(comm, C.c_void_p(sg.data_ptr()), sg.numel()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, rows) and torch.equal(cnt, cnt0) and torch.equal(sg, sg0)
+        assert lib.laff_allgather_rows(comm, None, None, 16) != 0 and b'null buffer' in lib.laff_last_error()
+    finally:
+        _lib.check(lib.laff_comm_destroy(comm))
