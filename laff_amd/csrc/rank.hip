@@ -553,13 +553,24 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     __shared__ int wsum[4];
     __shared__ int sel[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the ranks of this thread, f(value, index): 16-byte loads, eight of them in flight (the kernel is ONE workgroup and every pass is
+    // latency-bound: with 4-byte loads unrolled by 8 a pass over 40,000 ranks was five dependent round trips to L2, ~5 us; it is
+    // now two)
+    const bool vec = (((uintptr_t)r) & 15) == 0;
+    const int n4 = vec ? n >> 2 : 0;
+    auto each = [&](auto&& f) {
+#pragma unroll 8
+        for (int i4 = tid; i4 < n4; i4 += 1024) {
+            const int4 q = ((const int4*)r)[i4];
+            f(q.x + base, 4 * i4); f(q.y + base, 4 * i4 + 1); f(q.z + base, 4 * i4 + 2); f(q.w + base, 4 * i4 + 3);
+        }
+        for (int i = 4 * n4 + tid; i < n; i += 1024) f(r[i] + base, i);
+    };
     // ---- sums: exact integer counters, fp64 for the reciprocal sum
     unsigned long long c1 = 0, c5 = 0, c10 = 0, sum = 0;
     double isum = 0;
     int mx = 0, mn = 0x7fffffff;
-#pragma unroll 4
-    for (int i = tid; i < n; i += 1024) {
-        const int v = r[i] + base;
+    each([&](int v, int i) {
         if (ranks_out) ranks_out[i] = v;
         c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
         sum += (unsigned long long)(long long)v;
@@ -570,7 +581,7 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
         q = q * (2.0 - d * q);
         isum += q;
         mx = max(mx, v); mn = min(mn, v);
-    }
+    });
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         c1 += __shfl_xor(c1, o); c5 += __shfl_xor(c5, o); c10 += __shfl_xor(c10, o); sum += __shfl_xor(sum, o);
@@ -600,11 +611,10 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     for (int shift = ((32 - __clz(mx | 1) + 7) / 8 - 1) * 8; shift >= 0; shift -= 8) {
         for (int i = tid; i < 256 * 33; i += 1024) hist[i] = 0;
         __syncthreads();
-#pragma unroll 8
-        for (int i = tid; i < n; i += 1024) {
-            const unsigned v = (unsigned)(r[i] + base);
+        each([&](int vi, int) {
+            const unsigned v = (unsigned)vi;
             if ((v & mask) == prefix) atomicAdd(&hist[((v >> shift) & 255u) * 33 + rep], 1u);
-        }
+        });
         __syncthreads();
         // threads 0..255: bin totals, inclusive scan over the 256 bins, the owner of k publishes its digit
         int own = 0, inc = 0;
@@ -635,11 +645,9 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     if (n > 0 && (n & 1) == 0) {
         // sorted[k-1]: equals sorted[k] unless exactly k elements are smaller, then it is the largest of those
         int below = 0;
-#pragma unroll 8
-        for (int i = tid; i < n; i += 1024) {
-            const int v = r[i] + base;
+        each([&](int v, int) {
             if (v < med_lo) below = max(below, v);
-        }
+        });
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) below = max(below, __shfl_xor(below, o));
         __syncthreads();
