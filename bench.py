@@ -386,6 +386,7 @@ def main():
     for _ in range(max(1, args.warmup)):
         res = step(False)
     torch.cuda.synchronize()
+    eager_metrics = tuple(float(x) for x in res['metrics']) if res.get('metrics') is not None else None
     if not args.no_graph:
         try:
             if distributed:
@@ -417,7 +418,7 @@ def main():
             graph, runner = None, None
             torch.cuda.synchronize()
             res = step(False)
-    launch_mode = ('HIP graph replay, step k+1 enqueued while the host reads the metrics of step k' if graph is not None else
+    launch_mode = ('HIP graph replay, step k+1 enqueued while the host reads the metrics of step k; the two captures are checked against the eager step (16 replays) before the W warm-up replays' if graph is not None else
                    ('per-phase HIP graphs + eager RCCL, step k+1 issued while the host reads the metrics of step k'
                     if runner is not None else 'eager'))
 
@@ -461,6 +462,30 @@ def main():
             el = float(tt_.item())
         return el
 
+    # The W warm-up steps proper: the SAME steps as the timed ones (graph replays when the step is a graph), right in front of the
+    # timed region.  (The eager steps above only fill the allocator before the capture; the capture itself is host work during which
+    # the GPU idles and drops its clocks -- with the warm-up in front of it the first timed steps ran on a chip still ramping up:
+    # 1.19 ms per step over 20 steps against 1.115 sustained.)
+    if graph is not None:
+        # graph self-check: both captures, replayed alternately, must reproduce the eager step's seven metrics every time.  (16 replays
+        # = ~20 ms of device work; they also bring the chip out of the low clock state the capture leaves it in -- the first ~18 steps
+        # after an idle phase run 5-15 % slow: LAFF_BENCH_STEP_TRACE=1 prints the per-step intervals.)
+        want = eager_metrics
+        for k in range(16):
+            graphs[k % 2].replay()
+            torch.cuda.current_stream().synchronize()
+            check_metrics_flag(pins[k % 2])
+            got = tuple(pins[k % 2][:7].tolist())
+            if want is not None and got != want:
+                raise RuntimeError('graph replay %d gave metrics %s, the eager step %s' % (k, got, want))
+    for k in range(args.warmup):
+        if graph is not None:
+            graphs[k % 2].replay()
+        elif runner is not None:
+            step(False, async_metrics=True, runner=runner, state=state, slot=k % 2)
+        else:
+            step(False)
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -469,6 +494,7 @@ def main():
         # two steps in flight at most: step k is issued, then the host waits for step k-1 and reads ITS metrics buffer
         events = [torch.cuda.Event(), torch.cuda.Event()]
         seen = []
+        step_trace = [] if os.environ.get('LAFF_BENCH_STEP_TRACE') else None      # debugging: host time at which every step's result arrived
         for k in range(args.steps):
             if graph is not None and side is not None:
                 with torch.cuda.stream(side[k % 2]):
@@ -482,6 +508,8 @@ def main():
                 events[k % 2].record()
             if k:
                 events[(k - 1) % 2].synchronize()
+                if step_trace is not None:
+                    step_trace.append(time.perf_counter())
                 check_metrics_flag(pins[(k - 1) % 2])
                 seen.append(float(pins[(k - 1) % 2][0]))
         events[(args.steps - 1) % 2].synchronize()
@@ -498,6 +526,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    if (graph is not None or runner is not None) and step_trace:
+        print('step completion intervals (us): ' + ' '.join('%.0f' % (1e6 * (b - a)) for a, b in zip([t_start] + step_trace[:-1], step_trace)), file=sys.stderr)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

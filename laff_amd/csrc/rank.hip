@@ -196,6 +196,9 @@ __device__ __forceinline__ double exact_cos(const float* __restrict__ t, const f
         const float* th = t + (long)h * d;
         const float* vh = v + (long)h * d;
         double tt = 0.0, vv = 0.0, tv = 0.0;
+        // (unrolled: all 16 row loads of a d = 512 head in flight at once -- the resolve kernels are bound by the latency of these
+        // scattered 2 KB rows, and as a rolled loop a pair was eight dependent round trips; the order of the fma chain is unchanged)
+#pragma unroll 8
         for (int c = sl * 4; c < d; c += RG * 4) {
             const float4 a = *(const float4*)(th + c), b = *(const float4*)(vh + c);
             const double ax = a.x, ay = a.y, az = a.z, aw = a.w, bx = b.x, by = b.y, bz = b.z, bw = b.w;
