@@ -208,7 +208,7 @@ constexpr EpiStream make_epi_stream() {
                 if ((e & 3) == 3) push(OP_DSW, job, e >> 2);
                 // Job 0's four stores ride in job 1's element stream, one every fourth element: a store instruction is 8 rows x 128
                 // bytes, whole cache lines where the row pitch allows (as 16 rows x 64 bytes the same bytes left the chip at 3.2 TB/s,
-                // this way at 4.0: scratch/probe/stprobe), and a row of the slab is complete only behind the job's last quad.
+                // this way at 4.0: tools/probe/stprobe), and a row of the slab is complete only behind the job's last quad.
                 if (job > 0 && (e & 3) == 3) { push(OP_WAITR, 0, e >> 2); push(OP_STG, 0, e >> 2); }
             }
         }
@@ -314,8 +314,10 @@ constexpr EpiPlan make_epi_plan() {
 }  // namespace
 
 // MODE: GEMM_F16 / GEMM_BF16.  BANDED: exact-rank count + dumps.  HAVE_S: the fp32 score matrix is written (SCALE1: scale == 1).
-// Debug builds: -DLAFF_STRIP_SERIAL = the K loops alone, no epilogue (timing only, no output), -DLAFF_STRIP_TRACE = cycle stamps,
-// -DLAFF_STRIP_ABL = ablations of the K loop.
+// Debug builds (timing only unless noted; tools/debug/build_strip_variant.sh): -DLAFF_STRIP_SERIAL = the K loops alone, no epilogue;
+// -DLAFF_STRIP_ABL = 1 no fragment reads / 2 no refill DMA and barrier / 3 neither; -DLAFF_STRIP_NOCHK = no band test, -DLAFF_STRIP_NODUMPBODY
+// = band test without the dump, -DLAFF_STRIP_NOSTG = no score stores; -DLAFF_STRIP_TRACE = cycle stamps (correct results);
+// -DLAFF_STRIP_STFLAVOR="..." = cache policy bits of the score stores (correct results).
 template <int MODE, bool BANDED, bool HAVE_S, bool SCALE1>
 __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -660,7 +662,6 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                 // or un-prescaled fp16 operands): the accumulator quad goes to the slab as it is.
                 const unsigned wa = (arg & 1) ? slab_w1 : slab_w0;
                 const f32x16& x = acc[Q][rb];
-#ifndef LAFF_STRIP_NOSLAB
                 if constexpr (SCALE1) {
                     const f32x4 q4 = {x[4 * arg], x[4 * arg + 1], x[4 * arg + 2], x[4 * arg + 3]};
                     lds_write128<(arg >> 1) * 64 + rb * SLAB_JOB>(wa, q4);
@@ -678,7 +679,6 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                                      :: "v"(x[4 * arg]), "v"(x[4 * arg + 1]), "v"(x[4 * arg + 2]), "v"(x[4 * arg + 3]), "v"(wa), "s"(sc),
                                         "n"((arg >> 1) * 64 + rb * SLAB_JOB) : "v252", "v253", "v254", "v255", "memory");
                 }
-#endif
             } else if constexpr (op.kind == OP_CHK) {
                 // ONE test per block for both jobs (a ballot + scalar branch costs a lone wave ~60 cycles: 4 % of the launch as one per
                 // job).  In the band <=> 0 <= t <= hi - lo; the test here may only be WIDER than the band (laff_rank_resolve applies the
@@ -697,12 +697,10 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
             } else if constexpr (op.kind == OP_CNT) {
                 cnt[rb] += __builtin_popcount(sh[0]) + __builtin_popcount(sh[1]) + __builtin_popcount(sh[2]) + __builtin_popcount(sh[3]);
             } else if constexpr (op.kind == OP_DSR) {
-#ifndef LAFF_STRIP_NOSLAB
                 // (the empty statement keeps rr[arg] allocated from its store to here: hipcc, which does not know that statement is a
                 // store, handed the registers to the very next instruction while the store was still reading them)
                 asm volatile("" ::"v"(rr[arg]));
                 lds_read128<arg * 1024 + rb * SLAB_JOB>(rr[arg], slab_r);
-#endif
             } else if constexpr (op.kind == OP_WAITR) {
                 wait_lgkm<PLAN.wait_r[rb][arg]>();
             } else if constexpr (op.kind == OP_STG) {
@@ -756,11 +754,7 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                 if constexpr (J == BAR_J) {
 #if !(LAFF_STRIP_ABL & 2)
                     wait_lgkm<PLAN.lgkm_bar>();
-#ifdef LAFF_STRIP_VM0
-                    wait_vm<0>();
-#else
                     wait_vm<PLAN.vm_bar>();
-#endif
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
 #else
@@ -828,9 +822,7 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                 if (b < 12) STAMP(tb + 3 + b);
                 if (++b >= n) { mfma_drain_nops(); if (EPI) drain_to_lds(I1{}); break; }
             }
-#ifndef LAFF_STRIP_NODRAIN
             if (EPI) drain_rows(cb0 + n - 1);          // the last block's epilogue is the generic one
-#endif
         }
         // segment end: nothing of this wave may still be in flight towards LDS or the fragment registers
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
