@@ -46,6 +46,36 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.laff_packed_bytes(10, 512, 99, ctypes.byref(n)) == -1
     assert b'precision' in lib.laff_last_error()
     assert lib.laff_fuse(None, None, 1, 1, 1, 4, None, None, None, 0, None, None) == -1
+    # the collectives and the exact V2T count refuse null handles before touching RCCL or the GPU
+    assert lib.laff_comm_init(None, 0, 1, None, None) == -1 and b'laff_comm_init' in lib.laff_last_error()
+    assert lib.laff_allgather_rows(None, None, None, 16) == -1
+    assert lib.laff_allreduce_i32_sum(None, None, 4) == -1 and lib.laff_allreduce_f64_max(None, None, 4) == -1
+    assert lib.laff_comm_destroy(None) == 0
+    assert lib.laff_v2t_count_exact(None, None, 1, 1, 1, None, None, 1, None, None, 1, 4, None, None, None, None, None, 4) == -1
+
+
+def test_coalesce_batches_concatenates_what_a_loader_yields():
+    """model.retrieve() runs each tower once over the concatenated batches of any loader (laff_amd/model/model.py, coalesce_batches)."""
+    import numpy as np
+    import torch
+    from laff_amd.model.model import coalesce_batches
+    b1 = {'vis_feat_dict': {'a': torch.ones(2, 3), 'b': np.zeros((2, 1), np.float32)}, 'idxs': [0, 1], 'vis_ids': ('v0', 'v1'),
+          'vis_frame_feat_dict': {}, 'extra': None}
+    b2 = {'vis_feat_dict': {'a': 2 * torch.ones(1, 3), 'b': np.ones((1, 1), np.float32)}, 'idxs': [2], 'vis_ids': ('v2',),
+          'vis_frame_feat_dict': {}, 'extra': None}
+    out = coalesce_batches([b1, b2])
+    assert out['idxs'] == [0, 1, 2] and out['vis_ids'] == ['v0', 'v1', 'v2'] and out['extra'] is None and out['vis_frame_feat_dict'] == {}
+    assert out['vis_feat_dict']['a'].shape == (3, 3) and float(out['vis_feat_dict']['a'][2, 0]) == 2.0
+    assert out['vis_feat_dict']['b'].tolist() == [[0.0], [0.0], [1.0]]
+    assert coalesce_batches([]) is None
+    with pytest.raises(ValueError):
+        coalesce_batches([{'a': None}, {'b': None}])
+    with pytest.raises(ValueError):
+        coalesce_batches([None, torch.ones(1)])
+    with pytest.raises(TypeError):
+        coalesce_batches([3.0, 4.0])
+    with pytest.raises(RuntimeError):
+        coalesce_batches([torch.ones(2, 3), torch.ones(2, 4)])          # frame tensors padded to different lengths
 
 
 def test_cpu_tensors_are_refused():

@@ -195,3 +195,32 @@ def test_exact_v2t_positions_at_c1_shapes(strip_mode, prec):
     assert torch.equal(got, want)
     assert torch.equal(ops.v2t_count_exact(S, st, off, idx, per, list_cap=64), want)          # overflow -> one retry with the wanted size
     assert torch.equal(count, _fp64_count(Et, Ev, owner))
+
+
+@pytest.mark.parametrize('Nv,sizes,prec', [(97, (1,), 'fp16'), (130, (0, 3, 1), 'fp16'), (64, (7, 2, 8, 0, 5), 'bf16'), (40, (20, 0, 13), 'fp16x3'),
+                                           (33, (4,), 'fp32')])
+def test_exact_v2t_ragged_groups_vs_oracle(Nv, sizes, prec):
+    """Videos with 0 .. 20 captions in every mix (group passes of 4, 8 and 16 thresholds; columns without a caption), near-duplicate
+    embeddings so that many scores sit inside the band: counts equal those of oracle.txt2vis_matrix_f64 column by column."""
+    from laff_amd import ops
+    g = np.random.default_rng(Nv)
+    per = np.array([sizes[v % len(sizes)] for v in range(Nv)])
+    owner = np.repeat(np.arange(Nv), per).astype(np.int32)
+    perm = g.permutation(owner.size)
+    owner = owner[perm]                                            # captions of a video are not consecutive
+    Nt, H, d = owner.size, 2, 64
+    base = g.normal(0, 1, (1, H, d))
+    ev = (base + 0.05 * g.normal(0, 1, (Nv, H, d))).astype(np.float32)
+    et = (ev[owner] + 0.03 * g.normal(0, 1, (Nt, H, d))).astype(np.float32)
+    S64 = O.txt2vis_matrix_f64(et, ev)
+    want = np.array([int(np.sum(S64[:, owner[t]] > S64[t, owner[t]])) for t in range(Nt)])
+    Et, Ev = torch.as_tensor(et, device=DEV), torch.as_tensor(ev, device=DEV)
+    gt = torch.as_tensor(owner, device=DEV)
+    T, V = ops.pack_rows(Et, True, 1e-13, prec), ops.pack_rows(Ev, True, 1e-13, prec)
+    S, count, st = ops.exact_ranks(Et, Ev, T, V, gt)
+    order = np.argsort(owner, kind='stable').astype(np.int32)
+    off = np.zeros(Nv + 1, np.int32)
+    np.cumsum(np.bincount(owner, minlength=Nv), out=off[1:])
+    got = ops.v2t_count_exact(S, st, torch.as_tensor(off, device=DEV), torch.as_tensor(order, device=DEV), int(per.max()))
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    np.testing.assert_array_equal(count.cpu().numpy(), O.count_ranks(S64, owner) - 1)
