@@ -854,7 +854,8 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
-int g_strip_mode = 1;        // LAFF_STRIP (read when a ctx is created): 0 = never, 1 = where it is the faster kernel (default), 2 = wherever it can run
+int g_strip_mode = 1;        // LAFF_STRIP (read when a ctx is created): 0 = never, 1 = where it is the faster kernel (default), 2 = also bf16 operands and
+                             // smaller problems, 3 = wherever it can run (score rows of any pitch)
 int g_strip_map = 1;         // LAFF_STRIP_MAP: 0 = ranges to workgroups in order, 1 = grouped by column phase per XCD
 
 bool sim_strip_eligible(const GemmArgs& a, int mode, bool aligned) {
@@ -868,6 +869,10 @@ bool sim_strip_eligible(const GemmArgs& a, int mode, bool aligned) {
     if (a.count && !a.s_gt64) return false;
     if (a.out && ((a.ldo & 3) || (((uintptr_t)a.out) & 15))) return false;
     if (a.out && (long)SR * a.ldo * 4 >= (1ll << 32)) return false;     // the score rows of a strip are addressed through one raw buffer
+    // score rows whose pitch is not a multiple of 64 bytes: the 128-byte row pieces this kernel stores straddle lines at 16 / 32-byte
+    // offsets and the launch takes 1.9-2.6 x as long (50000 x 5001: 0.81 ms at ldo 5004 against 0.33 at 5008; tiled 0.46 / 0.39) -- the
+    // tiled kernel's 512-byte pieces mind much less.  (laff_amd.ops.alloc_scores pads the pitch to 128 bytes.)
+    if (a.out && (a.ldo & 15) && g_strip_mode < 3) return false;
     if ((long)a.nC * KBYTES >= (1ll << 32) || (a.nC + 63) / 64 > STRIP_MAX_GROUPS) return false;
     if (a.pairs && (16ull + 8ull * a.pair_cap) >= (1ull << 32)) return false;
     const long units = (long)((a.nR + SR - 1) / SR) * ((a.nC + CB - 1) / CB);

@@ -1,7 +1,7 @@
 """The strip form of the K = 512 similarity GEMM (laff_amd/csrc/sim_strip.hip: one wavefront per SIMD holding 64 text rows in
 registers, video blocks streamed through LDS) against the tiled kernel, the oracle and float64 ranks.  Both kernels sit behind the
 same entry points (laff_sim_gemm / laff_sim_gemm_banded, include/laff_hip.h); LAFF_STRIP picks: 0 = tiled only, 1 = strip where it
-is faster (default), 2 = strip wherever it can run."""
+is faster (default), 2 = also bf16 operands and smaller problems, 3 = wherever it can run (score rows of any pitch)."""
 import os
 
 import numpy as np
@@ -98,7 +98,7 @@ def test_strip_ragged_shapes_vs_oracle(strip_mode, Nt, Nv, ldo):
     Et, Ev, gt = _embeddings(Nt, Nv, 6.0, Nt + Nv)
     S64 = O.txt2vis_matrix_f64(Et.cpu().numpy(), Ev.cpu().numpy())
     want = O.count_ranks(S64, gt.cpu().numpy()) - 1
-    strip_mode(2)
+    strip_mode(3)
     S1, st1 = _run(ops, Et, Ev, gt, 'fp16', True, ldo=ldo)
     assert int(st1._header()[2]) >> 31 == 1, 'the strip kernel did not run'
     assert not st1.listed_pairs()[1]
@@ -110,7 +110,7 @@ def test_strip_ragged_shapes_vs_oracle(strip_mode, Nt, Nv, ldo):
     S0, st0 = _run(ops, Et, Ev, gt, 'fp16', True, ldo=ldo)
     assert int(st0._header()[2]) >> 31 == 0
     assert torch.equal(S0, S1)
-    strip_mode(2)
+    strip_mode(3)
     _, st2 = _run(ops, Et, Ev, gt, 'fp16', False)
     np.testing.assert_array_equal(st2.count.cpu().numpy(), want)
 
@@ -224,3 +224,16 @@ def test_exact_v2t_ragged_groups_vs_oracle(Nv, sizes, prec):
     got = ops.v2t_count_exact(S, st, torch.as_tensor(off, device=DEV), torch.as_tensor(order, device=DEV), int(per.max()))
     np.testing.assert_array_equal(got.cpu().numpy(), want)
     np.testing.assert_array_equal(count.cpu().numpy(), O.count_ranks(S64, owner) - 1)
+
+
+def test_misaligned_score_rows_go_to_the_tiled_kernel(strip_mode):
+    """A caller's score matrix whose row pitch is not a multiple of 64 bytes stays on the tiled kernel in the default mode (the strip
+    kernel's 128-byte row pieces would straddle lines at odd offsets: 2 x slower); same scores either way."""
+    from laff_amd import ops
+    Et, Ev, gt = _embeddings(40000, 10000, 9.0, 8)
+    strip_mode(1)
+    S_a, st_a = _run(ops, Et, Ev, gt, 'fp16', True, ldo=10008)
+    assert int(st_a._header()[2]) >> 31 == 0
+    S_b, st_b = _run(ops, Et, Ev, gt, 'fp16', True, ldo=10016)
+    assert int(st_b._header()[2]) >> 31 == 1
+    assert torch.equal(S_a, S_b) and torch.equal(st_a.count, st_b.count)
