@@ -237,3 +237,29 @@ def test_misaligned_score_rows_go_to_the_tiled_kernel(strip_mode):
     S_b, st_b = _run(ops, Et, Ev, gt, 'fp16', True, ldo=10016)
     assert int(st_b._header()[2]) >> 31 == 1
     assert torch.equal(S_a, S_b) and torch.equal(st_a.count, st_b.count)
+
+
+def test_strip_kernel_on_video_shards(strip_mode):
+    """The 'video' decomposition of laff_amd/dist.py on one GPU, strip kernel: every shard counts against the all-reduced (MAX) exact
+    ground-truth scores, most ground-truth columns lie outside the shard (col0 != 0); the summed counts are the float64 ranks."""
+    from laff_amd import ops
+    Et, Ev, gt = _embeddings(40000, 10000, 9.0, 12)
+    want = _fp64_count(Et, Ev, gt)
+    strip_mode(2)
+    T = ops.pack_rows(Et, True, 1e-13, 'fp16')
+    bounds = [0, 3333, 3334, 10000]
+    states = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        Evs = Ev[a:b].contiguous()
+        states.append(ops.rank_prepare(Et, Evs, T, ops.pack_rows(Evs, True, 1e-13, 'fp16'), gt, col0=a))
+    s_all = torch.stack([s.s_gt64 for s in states]).max(dim=0).values
+    total = torch.zeros(40000, dtype=torch.int32, device=DEV)
+    used = []
+    for s in states:
+        s.s_gt64.copy_(s_all)
+        S = ops.sim_gemm_banded(s, True)
+        used.append(int(s._header()[2]) >> 31)
+        total += ops.rank_resolve(s, S)
+        assert not s.listed_pairs()[1]
+    assert used == [1, 0, 1]                     # (the one-column shard is far below the strip kernel's size)
+    assert torch.equal(total, want)
