@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 13
+#define LAFF_ABI_VERSION 14
 
 enum {
     LAFF_OK = 0,
@@ -193,6 +193,32 @@ int laff_fuse(laff_ctx* ctx, const laff_plane* planes /*host array of L*/, int L
  * re-normalisation loss.cosine_sim applies (loss.py:33) is a no-op at 16-bit precision. */
 int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
                      const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale);
+
+/* laff_fuse_packed that ALSO does laff_rank_prepare's work for its rows (one head, d <= 512): the wavefront that has just produced a
+ * row measures the rounding error of the operand it emits (band) and, on the text side, scores the row exactly against its
+ * ground-truth video -- the 235 MB that laff_rank_prepare reads back at 40k x 10k are never read.  Two launches, videos first:
+ *   side 2 (video rows): band = band_v [((N + 3) & ~3) + ceil(N / 64)], per-column values written;
+ *   side 1 (text rows) : band = band_t [N]; Ev / Nv / band_v = the video side's E, row count and band_v (its 64-column block maxima
+ *                        are completed here: N * 16 >= Nv); s_gt64 [N] (-inf where gt_col - col0 is outside [0, Nv)), count [N]
+ *                        cleared, the header of `pairs` cleared.
+ * What the exact-rank pipeline needs afterwards is exactly what laff_rank_prepare leaves behind: laff_sim_gemm_banded and
+ * laff_rank_resolve follow unchanged; s_gt64 has the arithmetic of laff_rank_resolve's re-score (equal rows give bit-equal scores).
+ * LAFF_E_UNSUPPORTED for shapes this path does not cover (several heads, d > 512, no operand): call laff_rank_prepare instead. */
+typedef struct laff_rank_side {
+    int side;
+    const int* gt_col;
+    int col0;
+    const float* Ev;
+    int Nv;
+    double* s_gt64;
+    float* band;
+    float* band_v;
+    int* count;
+    unsigned* pairs;
+} laff_rank_side;
+int laff_fuse_packed_rank(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
+                          const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale,
+                          const laff_rank_side* rs /* NULL: plain laff_fuse_packed */);
 
 /* ---- a7: per-video frame attention of VisMutiTransformNetPlusFrameFeat (model/model.py:2163-2173) --------
  * V[B,d] = Attention_1 over the Fmax frames of each video; frames[B,Fmax,d] zero padded.

@@ -9,13 +9,18 @@ LIB_PATH = os.environ.get('LAFF_HIP_LIB') or os.path.join(_HERE, 'lib', 'liblaff
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class Plane(C.Structure):
     _fields_ = [('src', C.c_void_p), ('ld', C.c_int), ('tile', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p), ('act', C.c_int),
                 ('indptr', C.c_void_p), ('indices', C.c_void_p), ('values', C.c_void_p), ('wt', C.c_void_p), ('ldwt', C.c_int),
                 ('dk', C.c_int), ('bias', C.c_void_p), ('row_scale', C.c_void_p)]
+
+
+class RankSide(C.Structure):
+    _fields_ = [('side', C.c_int), ('gt_col', C.c_void_p), ('col0', C.c_int), ('Ev', C.c_void_p), ('Nv', C.c_int), ('s_gt64', C.c_void_p),
+                ('band', C.c_void_p), ('band_v', C.c_void_p), ('count', C.c_void_p), ('pairs', C.c_void_p)]
 
 
 class FcFusedProblem(C.Structure):
@@ -62,6 +67,7 @@ SIGNATURES = {
     'laff_plane_row_norms': (C.c_int, [_P, C.POINTER(Plane), _I, _I, _I, _I, C.c_uint, _P]),
     'laff_fuse': (C.c_int, [_P, C.POINTER(Plane), _I, _I, _I, _I, _P, _P, _P, C.c_uint, _P, _P]),
     'laff_fuse_packed': (C.c_int, [_P, C.POINTER(Plane), _I, _I, _I, _I, _P, _P, _P, C.c_uint, _P, _P, _P, _I, _F]),
+    'laff_fuse_packed_rank': (C.c_int, [_P, C.POINTER(Plane), _I, _I, _I, _I, _P, _P, _P, C.c_uint, _P, _P, _P, _I, _F, C.POINTER(RankSide)]),
     'laff_frame_fuse': (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, C.c_uint, _P]),
     'laff_packed_bytes': (C.c_int, [_I, _I, _I, C.POINTER(C.c_size_t)]),
     'laff_pack_rows': (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P]),

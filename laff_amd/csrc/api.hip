@@ -402,6 +402,9 @@ int laff_fc_act_bn_fused_grouped(laff_ctx* ctx, const laff_fc_fused_problem* pro
 
 int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
                      const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale);
+int laff_fuse_packed_rank(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
+                          const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale,
+                          const laff_rank_side* rs);
 
 int laff_fuse(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
               const float* gw, unsigned flags, float* E, float* attn_w) {
@@ -447,8 +450,27 @@ static int parse_planes(const laff_plane* planes, int L, int N, int H, int d, un
 
 int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
                      const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale) {
+    return laff_fuse_packed_rank(ctx, planes, L, N, H, d, w, b, gw, flags, E, attn_w, E16, precision, prescale, nullptr);
+}
+
+int laff_fuse_packed_rank(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
+                          const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale,
+                          const laff_rank_side* rs) {
     CHECK_CTX(ctx);
     if (N == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
+    if (rs) {
+        if (rs->side != 1 && rs->side != 2) return fail(LAFF_E_ARG, "laff_fuse_packed_rank: side must be 1 (text) or 2 (video)");
+        if (!E16 || H != 1 || d > 512)
+            return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed_rank: needs the 16-bit operand (E16), one head and d <= 512 (H=%d d=%d): use laff_rank_prepare", H, d);
+        if (!rs->band) return fail(LAFF_E_ARG, "laff_fuse_packed_rank: null band");
+        if (rs->side == 1) {
+            if (!rs->gt_col || !rs->Ev || !rs->s_gt64 || !rs->band_v || !rs->count || !rs->pairs)
+                return fail(LAFF_E_ARG, "laff_fuse_packed_rank: the text side needs gt_col, Ev, s_gt64, band_v, count and pairs");
+            if (rs->Nv < 1 || (long)N * 16 < rs->Nv)
+                return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed_rank: %d text rows cannot finish the block maxima of %d videos: use laff_rank_prepare", N, rs->Nv);
+            if (!aligned16(rs->Ev)) return fail(LAFF_E_ALIGN, "laff_fuse_packed_rank: Ev must be 16-byte aligned");
+        }
+    }
     if (E16 && precision != LAFF_PREC_FP16 && precision != LAFF_PREC_BF16)
         return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed: E16 is a single-plane operand (FP16 or BF16), got precision %d", precision);
     if (E16 && !aligned16(E16)) return fail(LAFF_E_ALIGN, "laff_fuse_packed: E16 must be 16-byte aligned");
@@ -464,6 +486,13 @@ int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int 
     a.head_major = any_gather ? 1 : 0;
     a.w = w; a.b = b; a.gw = gw; a.E = E; a.attn_w = attn_w;
     a.E16 = E16; a.e16_bf16 = precision == LAFF_PREC_BF16; a.e16_scale = prescale;
+    if (rs) {
+        a.rp_side = rs->side; a.rp_gt = rs->gt_col; a.rp_col0 = rs->col0; a.rp_Nv = rs->Nv; a.rp_Ev = rs->Ev; a.rp_sgt = rs->s_gt64;
+        a.rp_band = rs->band; a.rp_band_v = rs->band_v; a.rp_count = rs->count; a.rp_pairs = rs->pairs;
+        // the same constants as laff_rank_prepare (rank.hip: launch_rank_prepare) for a single-plane operand
+        a.rp_unit = precision == LAFF_PREC_BF16 ? 3.90625e-3f : 4.8828125e-4f;
+        a.rp_cacc = (float)((double)H * d * 1.1920929e-7 + 9.5367432e-7);
+    }
     DeviceGuard g(ctx->device);
     HIP_TRY(laff::launch_fuse(a, ctx->stream));
     return LAFF_OK;

@@ -117,6 +117,20 @@ struct FuseArgs {
     void* E16;            // optional [N, H*d] 16-bit GEMM operand (E * e16_scale), fp16 or bf16
     int e16_bf16;
     float e16_scale;
+    // laff_rank_prepare's work for these rows done by this launch (laff_fuse_packed_rank; H == 1, d <= 512, E16 given): the wave
+    // that has just produced a row measures its operand's rounding error (band) and, on the text side, scores it exactly against its
+    // ground-truth video (s_gt64) -- the rows are not read back by a separate launch.  rp_side 0 = off, 1 = text rows, 2 = video rows.
+    int rp_side;
+    const int* rp_gt;         // side 1: [N] ground-truth column of every text
+    int rp_col0, rp_Nv;       // side 1: the videos of this launch's partner are columns [col0, col0 + Nv)
+    const float* rp_Ev;       // side 1: their fp32 embeddings [Nv, d] (the E of the side-2 launch, complete before this one starts)
+    double* rp_sgt;           // side 1: s_gt64 [N]
+    float* rp_band;           // side 1: band_t [N];  side 2: band_v [((N + 3) & ~3) + ceil(N / 64)] (per column; the block maxima are
+                              //         finished by the side-1 launch, which runs behind this one)
+    float* rp_band_v;         // side 1: the partner's band_v
+    int* rp_count;            // side 1: [N], cleared
+    unsigned* rp_pairs;       // side 1: pair-list header, cleared
+    float rp_unit, rp_cacc;   // unit roundoff of the operand format, accumulation term of the band (see launch_rank_prepare)
 };
 hipError_t launch_fuse(const FuseArgs& a, hipStream_t st);
 hipError_t launch_plane_row_norms(const FuseArgs& a, float* out /*[L][N]*/, hipStream_t st);

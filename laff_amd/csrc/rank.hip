@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "exact_cos.h"
 
 namespace laff {
 
@@ -174,44 +175,6 @@ hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K
 // Rows / pairs are handled by GROUPS OF 16 LANES (4 per wavefront): lane sl of a group owns the float4 columns {64 j + 4 sl}.
 // Both kernels are latency-bound (a few KB per row, then a reduction), so 8 independent 16-byte loads per lane and a 4-step
 // reduction beat one wavefront per row; 95k listed pairs at C4 are 24k wavefronts instead of 95k.
-constexpr int RG = 16;                         // lanes per row / pair
-__device__ __forceinline__ double group_sum_f64(double v) {
-#pragma unroll
-    for (int o = RG / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float group_sum_f32(float v) {
-#pragma unroll
-    for (int o = RG / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-constexpr double COS_EPS = 1e-13 + 1e-14;      // loss.cosine_sim -> l2norm(eps=1e-13): X / (norm + eps + 1e-14)  (loss.py:8-13,30-34)
-
-// every lane of the group returns the same value; identical arithmetic (lane -> column map, fma order, reduction tree) wherever it
-// is called, so equal rows give bit-equal scores: a duplicate of the ground-truth video ties with it exactly and is not counted
-__device__ __forceinline__ double exact_cos(const float* __restrict__ t, const float* __restrict__ v, int H, int d, int sl) {
-    double s = 0.0;
-    for (int h = 0; h < H; ++h) {
-        const float* th = t + (long)h * d;
-        const float* vh = v + (long)h * d;
-        double tt = 0.0, vv = 0.0, tv = 0.0;
-        // (unrolled: all 16 row loads of a d = 512 head in flight at once -- the resolve kernels are bound by the latency of these
-        // scattered 2 KB rows, and as a rolled loop a pair was eight dependent round trips; the order of the fma chain is unchanged)
-#pragma unroll 8
-        for (int c = sl * 4; c < d; c += RG * 4) {
-            const float4 a = *(const float4*)(th + c), b = *(const float4*)(vh + c);
-            const double ax = a.x, ay = a.y, az = a.z, aw = a.w, bx = b.x, by = b.y, bz = b.z, bw = b.w;
-            tt = fma(ax, ax, tt); tt = fma(ay, ay, tt); tt = fma(az, az, tt); tt = fma(aw, aw, tt);
-            vv = fma(bx, bx, vv); vv = fma(by, by, vv); vv = fma(bz, bz, vv); vv = fma(bw, bw, vv);
-            tv = fma(ax, bx, tv); tv = fma(ay, by, tv); tv = fma(az, bz, tv); tv = fma(aw, bw, tv);
-        }
-        tt = group_sum_f64(tt); vv = group_sum_f64(vv); tv = group_sum_f64(tv);
-        s += tv / ((sqrt(tt) + COS_EPS) * (sqrt(vv) + COS_EPS));
-    }
-    return s / (double)H;
-}
-
 // 4 operand values of row `row` at column k (hi + lo for a split operand), PREC as LAFF_PREC_*
 template <int PREC>
 __device__ __forceinline__ void load_operand4(const void* __restrict__ op, long k, long plane, float (&x)[4]) {

@@ -41,14 +41,37 @@ class HipBackend:
         self.model, self.precision = model, precision
         ops.ctx_prepare_metrics(next(model.parameters()).device)     # scratch allocation outside any graph capture
 
-    def embed_both(self, vis_feats, txt_feats):
-        """Single-rank shortcut: both towers' FC projections in one grouped launch."""
+    def embed_both(self, vis_feats, txt_feats, fused=None):
+        """Single-rank shortcut: both towers' FC projections in one grouped launch.  fused (ops.FusedPrepare, from fused_prepare()):
+        the two fuse launches also do laff_rank_prepare's work for their rows (videos first: retrieval.embed's order)."""
         from .retrieval import embed
         self._emit_packed(True)
+        vl, tl = self.vis_layer(), self.txt_layer()
+        if fused is not None:
+            vl.rank_side, tl.rank_side = fused.video, fused.text
         try:
             return embed(self.model, vis_feats, txt_feats)
         finally:
             self._emit_packed(False)
+            if fused is not None:
+                vl.rank_side = tl.rank_side = None
+
+    def fused_prepare(self, Nt, Nv, heads, gt, col0=0):
+        """An ops.FusedPrepare when both towers end in a fuse launch that can carry laff_rank_prepare's work (one head of d <= 512,
+        fp16 / bf16 operand emitted by the launch; LAFF_FUSED_PREPARE=0 turns it off), else None (separate rank_prepare launch)."""
+        import os
+        if os.environ.get('LAFF_FUSED_PREPARE', '1') == '0':
+            return None
+        vl, tl = self.vis_layer(), self.txt_layer()
+        if not (self._fused_pack(vl) and self._fused_pack(tl)):
+            return None
+        d = getattr(tl, 'head_dim', None) or getattr(tl, 'embed_dim', None)
+        dv = getattr(vl, 'head_dim', None) or getattr(vl, 'embed_dim', None)
+        if d is None or d != dv or getattr(tl, 'multi_heads', 1) != 1 or getattr(vl, 'multi_heads', 1) != 1:
+            return None
+        if not ops.fused_prepare_eligible(Nt, Nv, heads, int(d), self.precision):
+            return None
+        return ops.FusedPrepare(Nt, Nv, gt, col0)
 
     def txt_layer(self):
         return self.model.txt_net.attention_layer
@@ -225,9 +248,18 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
     if hasattr(compute, 'set_unpacked'):
         compute.set_unpacked('txt' if comm else None)
     with torch.no_grad():
+        fused_box = [None]
         if not comm and hasattr(compute, 'embed_both'):
             def towers():
-                vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local)
+                # (single rank: laff_rank_prepare's work rides in the two fuse launches where they can carry it)
+                fused = compute.fused_prepare(Nt, Nv, heads, gt, v0) if (hasattr(compute, 'fused_prepare') and runner is None) else None
+                if fused is not None:
+                    vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local, fused)
+                    if fused.Et is None or fused.Ev is None:         # (a tower that did not end in the expected fuse launch)
+                        fused = None
+                else:
+                    vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local)
+                fused_box[0] = fused
                 return (txt_emb, compute.pack(txt_emb, compute.txt_layer()), vis_emb, compute.pack(vis_emb, compute.vis_layer()))
             txt_emb, T_all, vis_emb, V_local = run('towers', towers)
             Et_all = txt_emb
@@ -262,6 +294,8 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
                 Et = _compact(gathered, sizes, nmax, heads)
                 T = compute.pack_gathered(Et, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack_gathered(Et)
             elif hasattr(compute, 'embed_both'):
+                if fused_box[0] is not None:
+                    return fused_box[0].state()
                 Et, T = Et_all, T_all
             else:
                 Et = txt_emb

@@ -81,8 +81,10 @@ class Attention_1(nn.Module):
             planes = [(_full_width(p, heads, self.embed_dim), False, None, None) if p[1] else p for p in planes]
         packed = getattr(self, 'emit_packed', None)       # 'fp16' | 'bf16': also emit the GEMM operand (last_packed)
         rec = getattr(self, 'record_weights', False) if record_weights is None else record_weights
+        # rank_side (ops.FusedPrepare.video / .text, set for one pass by its owner): laff_rank_prepare's work for these rows rides along
+        side = getattr(self, 'rank_side', None) if packed else None
         res = ops.fuse(planes, 1, self.embed_dim, w, b, gw, flags, return_weights=rec, packed_precision=packed,
-                       l2norm_planes=l2norm_planes)
+                       l2norm_planes=l2norm_planes, rank_side=side)
         res = res if isinstance(res, tuple) else (res,)
         E = res[0]
         self.last_packed = res[-1] if packed else None
@@ -144,8 +146,9 @@ class Multi_head_MyApply_Attention(nn.Module):
         flags = ops.attention_flags(self.with_ave, self.mul, self.l2norm_each_head, self.split_head)
         packed = getattr(self, 'emit_packed', None)       # 'fp16' | 'bf16': also emit the GEMM operand (last_packed)
         rec = getattr(self, 'record_weights', False) if record_weights is None else record_weights
+        side = getattr(self, 'rank_side', None) if (packed and self.multi_heads == 1) else None
         res = ops.fuse(planes, self.multi_heads, self.head_dim, w, b, gw, flags, return_weights=rec, packed_precision=packed,
-                       l2norm_planes=l2norm_planes)
+                       l2norm_planes=l2norm_planes, rank_side=side)
         res = res if isinstance(res, tuple) else (res,)
         E = res[0]
         self.last_packed = res[-1] if packed else None

@@ -10,9 +10,9 @@ import torch
 
 from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
-                   FcProblem, FcSplitProblem, Plane, check, FcFusedProblem)
+                   FcProblem, FcSplitProblem, Plane, check, FcFusedProblem, RankSide)
 
-__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'topk_from_operands', 'alloc_scores', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts',
+__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'topk_from_operands', 'alloc_scores', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts', 'FusedPrepare', 'fused_prepare_eligible',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -329,7 +329,7 @@ def fc_act_bn_fused_grouped(problems):
     return outs
 
 
-def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=None, l2norm_planes=False):
+def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=None, l2norm_planes=False, rank_side=None):
     """planes: list of (src[N, ld-view], tile, scale, shift[, act]) -- act ('tanh' | 'relu' | 'sigmoid' | None) is applied to src
     before the affine (a projection that left its activation + BatchNorm to this kernel).  Returns E (N, H, d) [and softmax
     weights (N, H, L)].
@@ -391,9 +391,15 @@ def fuse(planes, H, d, w, b, gw, flags, return_weights=False, packed_precision=N
     if packed_precision is not None:
         prescale = default_prescale(packed_precision)
         buf = torch.empty((max(N * H * d * 2, 16),), device=dev, dtype=torch.uint8)
-        _call('fuse', lib.laff_fuse_packed, h, arr, L, N, H, d, _ptr(w), _ptr(b), _ptr(gw), flags, _ptr(E), _ptr(aw), _ptr(buf),
-              PREC[packed_precision], prescale)
+        rs = None
+        if rank_side is not None:
+            # FusedPrepare (below) for this side: laff_rank_prepare's work for these rows rides in this launch
+            rs = rank_side.side_struct(N, E)
+        _call('fuse', lib.laff_fuse_packed_rank, h, arr, L, N, H, d, _ptr(w), _ptr(b), _ptr(gw), flags, _ptr(E), _ptr(aw), _ptr(buf),
+              PREC[packed_precision], prescale, rs)
         packed = Packed(buf, N, H * d, packed_precision, prescale)
+        if rank_side is not None:
+            rank_side.done(E, packed)
     else:
         _call('fuse', lib.laff_fuse, h, arr, L, N, H, d, _ptr(w), _ptr(b), _ptr(gw), flags, _ptr(E), _ptr(aw))
     out = (E, aw) if return_weights else (E,)
@@ -590,6 +596,64 @@ def _emb3(E, name):
 
 def default_pair_cap(Nt):
     return max(1 << 20, 64 * int(Nt))
+
+
+def fused_prepare_eligible(Nt, Nv, H, d, precision):
+    """laff_fuse_packed_rank covers one head of d <= 512 with a single-plane 16-bit operand; the text launch finishes the videos'
+    64-column block maxima (16 Nt >= Nv)."""
+    return H == 1 and d <= 512 and d % 4 == 0 and precision in ('fp16', 'bf16') and Nv >= 1 and 16 * Nt >= Nv
+
+
+class FusedPrepare:
+    """laff_rank_prepare's outputs produced by the two fuse launches of a pass (laff_fuse_packed_rank, videos first): allocate with the
+    problem's sizes, hand `.video` / `.text` to the fuse calls of the two towers as `rank_side`, then `.state()` is the RankState
+    rank_prepare would have returned."""
+
+    class _Side:
+        def __init__(self, owner, side):
+            self.owner, self.side = owner, side
+
+        def side_struct(self, N, E):
+            o = self.owner
+            if self.side == 2:
+                if N != o.Nv:
+                    raise ValueError('the video tower produced %d rows, FusedPrepare was made for %d' % (N, o.Nv))
+                return RankSide(2, None, 0, None, 0, None, o.band_v.data_ptr(), None, None, None)
+            if N != o.Nt or o.Ev is None:
+                raise ValueError('the text tower must run behind the video tower (%d rows, FusedPrepare made for %d)' % (N, o.Nt))
+            return RankSide(1, o.gt_col.data_ptr(), o.col0, o.Ev.data_ptr(), o.Nv, o.s_gt64.data_ptr(), o.band_t.data_ptr(),
+                            o.band_v.data_ptr(), o.count.data_ptr(), o.pairs.data_ptr())
+
+        def done(self, E, packed):
+            if self.side == 2:
+                self.owner.Ev, self.owner.V = E, packed
+            else:
+                self.owner.Et, self.owner.T = E, packed
+
+    def __init__(self, Nt, Nv, gt_col, col0=0, pair_cap=None):
+        _dev(gt_col, 'gt_col', torch.int32)
+        if gt_col.numel() != Nt or not gt_col.is_contiguous():
+            raise ValueError('gt_col must be a contiguous int32 vector of %d' % Nt)
+        if gt_col.data_ptr() % 16:
+            gt_col = gt_col.clone()
+        dev = gt_col.device
+        cap = (int(pair_cap) if pair_cap is not None else default_pair_cap(Nt)) & ~3
+        if cap < 4:
+            raise ValueError('pair_cap must be >= 4')
+        self.Nt, self.Nv, self.gt_col, self.col0, self.pair_cap = Nt, Nv, gt_col, int(col0), cap
+        self.s_gt64 = torch.empty((Nt + 2,), device=dev, dtype=torch.float64)[:Nt]
+        self.band_t = torch.empty((Nt + 4,), device=dev, dtype=torch.float32)
+        self.band_v = torch.empty((((Nv + 3) & ~3) + (Nv + 63) // 64 + 4,), device=dev, dtype=torch.float32)
+        self.count = torch.empty((Nt,), device=dev, dtype=torch.int32)
+        self.pairs = torch.empty((4 + 2 * cap,), device=dev, dtype=torch.int32)
+        self.Et = self.Ev = self.T = self.V = None
+        self.video, self.text = self._Side(self, 2), self._Side(self, 1)
+
+    def state(self):
+        if self.Et is None or self.Ev is None:
+            raise RuntimeError('FusedPrepare.state(): both fuse launches must have run (videos first)')
+        return RankState(self.Et, self.Ev, self.T, self.V, 1, self.gt_col, self.col0, self.s_gt64, self.band_t, self.band_v,
+                         self.count, self.pairs, self.pair_cap)
 
 
 def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None):

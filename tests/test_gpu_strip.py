@@ -263,3 +263,45 @@ def test_strip_kernel_on_video_shards(strip_mode):
         assert not s.listed_pairs()[1]
     assert used == [1, 0, 1]                     # (the one-column shard is far below the strip kernel's size)
     assert torch.equal(total, want)
+
+
+@pytest.mark.parametrize('prec', ['fp16', 'bf16'])
+def test_fused_prepare_leaves_what_rank_prepare_leaves(prec):
+    """laff_fuse_packed_rank: the two fuse launches of a pass (videos first) do laff_rank_prepare's work -- s_gt64 BIT-equal (same
+    arithmetic as the re-score), bands equal to rounding (never narrower than 1 - 1e-6 of rank_prepare's), count / list header cleared
+    -- and the pipeline that follows gives the float64 ranks."""
+    from laff_amd import ops
+    Nt, Nv, d, L = 6000, 2100, 512, 3
+    g = torch.Generator(device=DEV).manual_seed(5)
+    z = torch.randn(Nv, 32, generator=g, device=DEV)
+    gt = (torch.arange(Nt, device=DEV) * 31 % Nv).to(torch.int32)
+    w = torch.randn(1, d, generator=g, device=DEV) * 0.05
+    b, gw = torch.zeros(1, device=DEV), torch.ones(1, device=DEV)
+
+    def planes(n, lat):
+        return [(lat @ torch.randn(32, d, generator=g, device=DEV) + 3.0 * torch.randn(n, d, generator=g, device=DEV), False, None, None)
+                for _ in range(L)]
+    pv, pt = planes(Nv, z), planes(Nt, z[gt.long()])
+    flags = ops.attention_flags(True, False)
+    fp = ops.FusedPrepare(Nt, Nv, gt)
+    fp.count.fill_(7)
+    fp.pairs[:4] = 9
+    Ev, V = ops.fuse(pv, 1, d, w, b, gw, flags, packed_precision=prec, rank_side=fp.video)
+    Et, T = ops.fuse(pt, 1, d, w, b, gw, flags, packed_precision=prec, rank_side=fp.text)
+    st = fp.state()
+    ref = ops.rank_prepare(Et, Ev, T, V, gt)
+    assert torch.equal(st.s_gt64, ref.s_gt64)
+    assert int(st.count.abs().sum()) == 0 and st.pairs[:4].tolist() == [0, 0, 0, 0]
+    nb = ((Nv + 3) & ~3) + (Nv + 63) // 64
+    for a, r in ((st.band_t[:Nt], ref.band_t[:Nt]), (st.band_v[:Nv], ref.band_v[:Nv]), (st.band_v[(Nv + 3) & ~3:nb], ref.band_v[(Nv + 3) & ~3:nb])):
+        assert float(((a - r).abs() / r).max()) < 1e-5 and bool((a >= r * (1 - 1e-6)).all())
+    S = ops.sim_gemm_banded(st, True)
+    ops.rank_resolve(st, S)
+    assert not st.listed_pairs()[1]
+    assert torch.equal(st.count, _fp64_count(Et, Ev, gt))
+    # a text whose video is not among these columns: -inf, like rank_prepare
+    fp2 = ops.FusedPrepare(Nt, Nv, gt, col0=100)
+    ops.fuse(pv, 1, d, w, b, gw, flags, packed_precision=prec, rank_side=fp2.video)
+    ops.fuse(pt, 1, d, w, b, gw, flags, packed_precision=prec, rank_side=fp2.text)
+    out = (gt < 100) | (gt >= 100 + Nv)
+    assert bool(torch.isneginf(fp2.s_gt64[out]).all()) and bool(torch.isfinite(fp2.s_gt64[~out]).all())
