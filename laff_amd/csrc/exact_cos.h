@@ -26,7 +26,7 @@ constexpr double COS_EPS = 1e-13 + 1e-14;      // loss.cosine_sim -> l2norm(eps=
 // load_t(h, c): the float4 of the text row at head h, column c (a global row in rank.hip, the LDS copy of the row the fuse kernel has
 // just produced in fuse.hip); v: the video row in global memory.
 template <typename LoadT>
-__device__ __forceinline__ double exact_cos_with(LoadT&& load_t, const float* __restrict__ v, int H, int d, int sl) {
+__device__ __forceinline__ double exact_cos_with(LoadT&& load_t, const float* __restrict__ v, int H, int d, int sl, double* tt_last = nullptr) {
     double s = 0.0;
     for (int h = 0; h < H; ++h) {
         const float* vh = v + (long)h * d;
@@ -42,6 +42,7 @@ __device__ __forceinline__ double exact_cos_with(LoadT&& load_t, const float* __
             tv = fma(ax, bx, tv); tv = fma(ay, by, tv); tv = fma(az, bz, tv); tv = fma(aw, bw, tv);
         }
         tt = group_sum_f64(tt); vv = group_sum_f64(vv); tv = group_sum_f64(tv);
+        if (tt_last) *tt_last = tt;                                  // (|t_h|^2 of the last head, for callers that need the norm too)
         s += tv / ((sqrt(tt) + COS_EPS) * (sqrt(vv) + COS_EPS));
     }
     return s / (double)H;

@@ -179,73 +179,67 @@ __device__ __forceinline__ void softmax_L(float (&lg)[L]) {
     for (int l = 0; l < L; ++l) lg[l] *= inv;
 }
 
-// ---- laff_rank_prepare's work for a row, by the wave that has just produced it (FuseArgs::rp_*; H == 1) ------------------------
-//   band: q = |operand / prescale - e / (|e| + eps)|_2 of the 16-bit operand this launch emits, measured on the registers (fp64 sums),
+// ---- laff_rank_prepare's work for the rows of a block, right behind their production (FuseArgs::rp_*; H == 1) -----------------------
+//   band: q = |operand / prescale - e / (|e| + eps)|_2 of the 16-bit operand this launch emits for the row (fp64 sums),
 //         band_t = q (1 + u) 1.0001 + c_acc,  band_v = q 1.0001  -- rank.hip has the derivation (rank_prepare_kernel does the same from memory);
-//   text side: s_gt64 = exact(row, its ground-truth video) with exact_cos_with's arithmetic -- the row goes through LDS so that the
-//         16-lane groups walk it exactly as laff_rank_resolve walks a row in global memory: bit-equal scores for equal rows --, the
-//         count accumulator and the pair-list header cleared, and (blocks [0, ceil(Nv / 64))) the maxima of the partner's band_v over its
-//         aligned 64-column blocks, which the video-side launch in front of this one has completed per column.
+//   text side: s_gt64 = exact(row, its ground-truth video) with exact_cos_with's arithmetic -- 16-lane groups walk the row exactly as
+//         laff_rank_resolve walks a row in global memory: bit-equal scores for equal rows --, the count accumulator and the pair-list
+//         header cleared, and (blocks [0, ceil(Nv / 64))) the maxima of the partner's band_v over its aligned 64-column blocks, which
+//         the video-side launch in front of this one has completed per column.
 template <int NCH>
 __device__ __forceinline__ void rank_side(const FuseArgs& a, long n, int lane, const float4 (&g)[NCH]) {
     __shared__ __attribute__((aligned(16))) float erow[4][256 * NCH];
     const int wave = threadIdx.x >> 6, d = a.d;
-    // fp64 norm of the row as stored (the embedding E), then the distance of the operand from the normalised row
-    double tt = 0.0;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        if (j * 256 + lane * 4 < d) {
-            const double x = g[j].x, y = g[j].y, z = g[j].z, w = g[j].w;
-            tt = fma(x, x, tt); tt = fma(y, y, tt); tt = fma(z, z, tt); tt = fma(w, w, tt);
-        }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) tt += __shfl_xor(tt, o);
-    const double inv_n = 1.0 / (sqrt(tt) + COS_EPS), inv_ps = 1.0 / (double)a.e16_scale;
-    double q2 = 0.0;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-        if (j * 256 + lane * 4 < d) {
-            const float v4[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x16 = a.e16_bf16 ? (float)(__bf16)(v4[e] * a.e16_scale) : (float)(_Float16)(v4[e] * a.e16_scale);
-                const double dlt = (double)x16 * inv_ps - (double)v4[e] * inv_n;
-                q2 = fma(dlt, dlt, q2);
-            }
-        }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) q2 += __shfl_xor(q2, o);
-    const float q = (float)sqrt(q2);
-    if (a.rp_side == 2) {
-        if (lane == 0) a.rp_band[n] = q * 1.0001f;
-        return;
-    }
-    if (lane == 0) {
-        a.rp_band[n] = q * (1.0f + a.rp_unit) * 1.0001f + a.rp_cacc;
-        a.rp_count[n] = 0;
-    }
-    // the exact ground-truth scores of the block's four rows by ONE wavefront, a 16-lane group per row (as rank_prepare_kernel and
-    // laff_rank_resolve walk rows: a wave per row spent four times the instructions on this part and made the launch 46 us longer
-    // than the 39 us rank_prepare launch it replaces)
+    // The block's four rows go through LDS and ONE wavefront does the fp64 work, a 16-lane group per row (as rank_prepare_kernel and
+    // laff_rank_resolve walk rows): with every wave measuring and scoring its own row the launch grew by 46 us -- more than the 39 us
+    // rank_prepare launch it replaces.
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
         if (j * 256 + lane * 4 < d) *(float4*)(&erow[wave][j * 256 + lane * 4]) = g[j];
     __syncthreads();                                               // (waves of a last, partial block that have no row have exited)
     if (wave != 0) return;
-    {
-        const int grp = lane >> 4, sl = lane & (RG - 1);
-        const long nr = n + grp;                                   // wave 0 holds the block's first row
-        const bool have = nr < a.N;
+    const int grp = lane >> 4, sl = lane & (RG - 1);
+    const long nr = n + grp;                                       // wave 0 holds the block's first row
+    const bool have = nr < a.N;
+    const float* er = erow[grp];
+    auto row = [&](int, int col) { return *(const float4*)(er + col); };
+    double tt = 0.0;
+    if (a.rp_side == 1) {
         const int c = have ? a.rp_gt[nr] - a.rp_col0 : -1;
         const bool own = c >= 0 && c < a.rp_Nv;
-        const float* er = erow[grp];
         // (groups without a ground-truth row here walk row 0 of the partner: the shuffles of the reduction stay convergent)
-        const double sg = exact_cos_with([&](int, int col) { return *(const float4*)(er + col); }, a.rp_Ev + (long)(own ? c : 0) * d, 1, d, sl);
-        if (have && sl == 0) a.rp_sgt[nr] = own ? sg : -INFINITY;
+        const double sg = exact_cos_with(row, a.rp_Ev + (long)(own ? c : 0) * d, 1, d, sl, &tt);
+        if (have && sl == 0) {
+            a.rp_sgt[nr] = own ? sg : -INFINITY;
+            a.rp_count[nr] = 0;
+        }
+    } else {
+        for (int col = sl * 4; col < d; col += RG * 4) {
+            const float4 e = row(0, col);
+            const double x = e.x, y = e.y, z = e.z, w = e.w;
+            tt = fma(x, x, tt); tt = fma(y, y, tt); tt = fma(z, z, tt); tt = fma(w, w, tt);
+        }
+        tt = group_sum_f64(tt);
     }
+    // q = |operand / prescale - e / (|e| + eps)|_2 of the operand this launch has emitted for the row
+    const double inv_n = 1.0 / (sqrt(tt) + COS_EPS), inv_ps = 1.0 / (double)a.e16_scale;
+    double q2 = 0.0;
+    for (int col = sl * 4; col < d; col += RG * 4) {
+        const float4 e4 = row(0, col);
+        const float v4[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x16 = a.e16_bf16 ? (float)(__bf16)(v4[e] * a.e16_scale) : (float)(_Float16)(v4[e] * a.e16_scale);
+            const double dlt = (double)x16 * inv_ps - (double)v4[e] * inv_n;
+            q2 = fma(dlt, dlt, q2);
+        }
+    }
+    const float q = (float)sqrt(group_sum_f64(q2));
+    if (have && sl == 0) a.rp_band[nr] = a.rp_side == 1 ? q * (1.0f + a.rp_unit) * 1.0001f + a.rp_cacc : q * 1.0001f;
+    if (a.rp_side != 1) return;
     if (blockIdx.x == 0 && threadIdx.x < 4) a.rp_pairs[threadIdx.x] = 0u;
     const int nblk = (a.rp_Nv + 63) >> 6;
-    if ((int)blockIdx.x < nblk && wave == 0) {
+    if ((int)blockIdx.x < nblk) {
         const int v = (int)blockIdx.x * 64 + lane;
         float m = v < a.rp_Nv ? a.rp_band_v[v] : 0.0f;
         m = wave_max(m);
