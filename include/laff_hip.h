@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 14
+#define LAFF_ABI_VERSION 15
 
 enum {
     LAFF_OK = 0,
@@ -194,7 +194,7 @@ int laff_fuse(laff_ctx* ctx, const laff_plane* planes /*host array of L*/, int L
 int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
                      const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale);
 
-/* laff_fuse_packed that ALSO does laff_rank_prepare's work for its rows (one head, d <= 512): the wavefront that has just produced a
+/* laff_fuse_packed that ALSO does laff_rank_prepare's work for its rows (split heads of d <= 512): the wavefront that has just produced a
  * row measures the rounding error of the operand it emits (band) and, on the text side, scores the row exactly against its
  * ground-truth video -- the 235 MB that laff_rank_prepare reads back at 40k x 10k are never read.  Two launches, videos first:
  *   side 2 (video rows): band = band_v [((N + 3) & ~3) + ceil(N / 64)], per-column values written;
@@ -203,7 +203,7 @@ int laff_fuse_packed(laff_ctx* ctx, const laff_plane* planes, int L, int N, int 
  *                        cleared, the header of `pairs` cleared.
  * What the exact-rank pipeline needs afterwards is exactly what laff_rank_prepare leaves behind: laff_sim_gemm_banded and
  * laff_rank_resolve follow unchanged; s_gt64 has the arithmetic of laff_rank_resolve's re-score (equal rows give bit-equal scores).
- * LAFF_E_UNSUPPORTED for shapes this path does not cover (several heads, d > 512, no operand): call laff_rank_prepare instead. */
+ * LAFF_E_UNSUPPORTED for shapes this path does not cover (d > 512, unsplit heads, no operand): call laff_rank_prepare instead. */
 typedef struct laff_rank_side {
     int side;
     const int* gt_col;
@@ -215,6 +215,8 @@ typedef struct laff_rank_side {
     float* band_v;
     int* count;
     unsigned* pairs;
+    double* partials;      /* H > 1: scratch [N][H][2] (the per-head terms of a row come from several workgroups; the last arrival sums them */
+    unsigned* tickets;     /*        in head order: the arithmetic of laff_rank_resolve's re-score); [N], cleared by the call */
 } laff_rank_side;
 int laff_fuse_packed_rank(laff_ctx* ctx, const laff_plane* planes, int L, int N, int H, int d, const float* w, const float* b,
                           const float* gw, unsigned flags, float* E, float* attn_w, void* E16, int precision, float prescale,

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get('LAFF_HIP_LIB') or os.path.join(_HERE, 'lib', 'liblaff
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class Plane(C.Structure):
@@ -20,7 +20,8 @@ class Plane(C.Structure):
 
 class RankSide(C.Structure):
     _fields_ = [('side', C.c_int), ('gt_col', C.c_void_p), ('col0', C.c_int), ('Ev', C.c_void_p), ('Nv', C.c_int), ('s_gt64', C.c_void_p),
-                ('band', C.c_void_p), ('band_v', C.c_void_p), ('count', C.c_void_p), ('pairs', C.c_void_p)]
+                ('band', C.c_void_p), ('band_v', C.c_void_p), ('count', C.c_void_p), ('pairs', C.c_void_p), ('partials', C.c_void_p),
+                ('tickets', C.c_void_p)]
 
 
 class FcFusedProblem(C.Structure):

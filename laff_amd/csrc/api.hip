@@ -460,8 +460,9 @@ int laff_fuse_packed_rank(laff_ctx* ctx, const laff_plane* planes, int L, int N,
     if (N == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (rs) {
         if (rs->side != 1 && rs->side != 2) return fail(LAFF_E_ARG, "laff_fuse_packed_rank: side must be 1 (text) or 2 (video)");
-        if (!E16 || H != 1 || d > 512)
-            return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed_rank: needs the 16-bit operand (E16), one head and d <= 512 (H=%d d=%d): use laff_rank_prepare", H, d);
+        if (!E16 || d > 512 || (flags & LAFF_ATT_NO_SPLIT_HEAD))
+            return fail(LAFF_E_UNSUPPORTED, "laff_fuse_packed_rank: needs the 16-bit operand (E16) and split heads of d <= 512 (H=%d d=%d): use laff_rank_prepare", H, d);
+        if (H > 1 && (!rs->partials || !rs->tickets)) return fail(LAFF_E_ARG, "laff_fuse_packed_rank: several heads need the partials / tickets scratch");
         if (!rs->band) return fail(LAFF_E_ARG, "laff_fuse_packed_rank: null band");
         if (rs->side == 1) {
             if (!rs->gt_col || !rs->Ev || !rs->s_gt64 || !rs->band_v || !rs->count || !rs->pairs)
@@ -489,11 +490,13 @@ int laff_fuse_packed_rank(laff_ctx* ctx, const laff_plane* planes, int L, int N,
     if (rs) {
         a.rp_side = rs->side; a.rp_gt = rs->gt_col; a.rp_col0 = rs->col0; a.rp_Nv = rs->Nv; a.rp_Ev = rs->Ev; a.rp_sgt = rs->s_gt64;
         a.rp_band = rs->band; a.rp_band_v = rs->band_v; a.rp_count = rs->count; a.rp_pairs = rs->pairs;
+        a.rp_part = rs->partials; a.rp_ticket = rs->tickets;
         // the same constants as laff_rank_prepare (rank.hip: launch_rank_prepare) for a single-plane operand
         a.rp_unit = precision == LAFF_PREC_BF16 ? 3.90625e-3f : 4.8828125e-4f;
         a.rp_cacc = (float)((double)H * d * 1.1920929e-7 + 9.5367432e-7);
     }
     DeviceGuard g(ctx->device);
+    if (rs && H > 1) HIP_TRY(hipMemsetAsync(rs->tickets, 0, (size_t)N * sizeof(unsigned), ctx->stream));
     HIP_TRY(laff::launch_fuse(a, ctx->stream));
     return LAFF_OK;
 }

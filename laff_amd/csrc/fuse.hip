@@ -187,32 +187,37 @@ __device__ __forceinline__ void softmax_L(float (&lg)[L]) {
 //         header cleared, and (blocks [0, ceil(Nv / 64))) the maxima of the partner's band_v over its aligned 64-column blocks, which
 //         the video-side launch in front of this one has completed per column.
 template <int NCH>
-__device__ __forceinline__ void rank_side(const FuseArgs& a, long n, int lane, const float4 (&g)[NCH]) {
+__device__ __forceinline__ void rank_side(const FuseArgs& a, long n, int h, int lane, const float4 (&g)[NCH]) {
     __shared__ __attribute__((aligned(16))) float erow[4][256 * NCH];
-    const int wave = threadIdx.x >> 6, d = a.d;
-    // The block's four rows go through LDS and ONE wavefront does the fp64 work, a 16-lane group per row (as rank_prepare_kernel and
-    // laff_rank_resolve walk rows): with every wave measuring and scoring its own row the launch grew by 46 us -- more than the 39 us
-    // rank_prepare launch it replaces.
+    __shared__ long item_n[4];
+    __shared__ int item_h[4];
+    const int wave = threadIdx.x >> 6, d = a.d, H = a.H;
+    // The block's four (row, head) items go through LDS and ONE wavefront does the fp64 work, a 16-lane group per item (as
+    // rank_prepare_kernel and laff_rank_resolve walk rows): with every wave measuring and scoring its own item the launch grew by 46 us
+    // at C4 -- more than the 39 us rank_prepare launch it replaces.
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
         if (j * 256 + lane * 4 < d) *(float4*)(&erow[wave][j * 256 + lane * 4]) = g[j];
-    __syncthreads();                                               // (waves of a last, partial block that have no row have exited)
+    if (wave == 0 && lane < 4) item_n[lane] = -1;                   // (waves of a last, partial block that have no item have exited)
+    __syncthreads();
+    if (lane == 0) { item_n[wave] = n; item_h[wave] = h; }
+    __syncthreads();
     if (wave != 0) return;
     const int grp = lane >> 4, sl = lane & (RG - 1);
-    const long nr = n + grp;                                       // wave 0 holds the block's first row
-    const bool have = nr < a.N;
+    const long nr = item_n[grp];
+    const bool have = nr >= 0;
+    const int hr = have ? item_h[grp] : 0;
+    const long K = (long)H * d;
     const float* er = erow[grp];
     auto row = [&](int, int col) { return *(const float4*)(er + col); };
-    double tt = 0.0;
+    double tt = 0.0, ch = 0.0;
+    bool own = false;
     if (a.rp_side == 1) {
         const int c = have ? a.rp_gt[nr] - a.rp_col0 : -1;
-        const bool own = c >= 0 && c < a.rp_Nv;
+        own = c >= 0 && c < a.rp_Nv;
+        // one head's term of exact(): exact_cos_with on the head slice with H = 1 returns tv / ((|t_h| + eps)(|v_h| + eps)) unchanged.
         // (groups without a ground-truth row here walk row 0 of the partner: the shuffles of the reduction stay convergent)
-        const double sg = exact_cos_with(row, a.rp_Ev + (long)(own ? c : 0) * d, 1, d, sl, &tt);
-        if (have && sl == 0) {
-            a.rp_sgt[nr] = own ? sg : -INFINITY;
-            a.rp_count[nr] = 0;
-        }
+        ch = exact_cos_with(row, a.rp_Ev + (long)(own ? c : 0) * K + (long)hr * d, 1, d, sl, &tt);
     } else {
         for (int col = sl * 4; col < d; col += RG * 4) {
             const float4 e = row(0, col);
@@ -221,7 +226,7 @@ __device__ __forceinline__ void rank_side(const FuseArgs& a, long n, int lane, c
         }
         tt = group_sum_f64(tt);
     }
-    // q = |operand / prescale - e / (|e| + eps)|_2 of the operand this launch has emitted for the row
+    // q_h^2 = |operand / prescale - e / (|e| + eps)|^2 over the head, of the operand this launch has emitted
     const double inv_n = 1.0 / (sqrt(tt) + COS_EPS), inv_ps = 1.0 / (double)a.e16_scale;
     double q2 = 0.0;
     for (int col = sl * 4; col < d; col += RG * 4) {
@@ -234,8 +239,45 @@ __device__ __forceinline__ void rank_side(const FuseArgs& a, long n, int lane, c
             q2 = fma(dlt, dlt, q2);
         }
     }
-    const float q = (float)sqrt(group_sum_f64(q2));
-    if (have && sl == 0) a.rp_band[nr] = a.rp_side == 1 ? q * (1.0f + a.rp_unit) * 1.0001f + a.rp_cacc : q * 1.0001f;
+    q2 = group_sum_f64(q2);
+    bool last = have;                                              // this group finishes the row (all of it with one head)
+    if (H > 1) {
+        // several heads: the per-head terms of a row come from up to H blocks.  Every item leaves {term, q_h^2} in the scratch and
+        // takes a ticket; the H-th arrival sums the terms IN HEAD ORDER -- the sequence of exact_cos_with over the heads, so that
+        // s_gt64 keeps the arithmetic of laff_rank_resolve whatever order the blocks ran in.
+        // (agent-scope relaxed atomics, ordered by waiting for the stores' acknowledgement: a release / acquire fence pair here writes
+        // back and invalidates the XCD's L2 once per item -- it made the launch 8 x longer)
+        int tk = 0;
+        if (have && sl == 0) {
+            double* p = a.rp_part + ((size_t)nr * H + hr) * 2;
+            __hip_atomic_store(p, ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p + 1, q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tk = (int)__hip_atomic_fetch_add(a.rp_ticket + nr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        tk = __shfl(tk, lane & ~(RG - 1));
+        last = have && tk == H - 1;
+        if (last) {
+            double* p = a.rp_part + (size_t)nr * H * 2;
+            double ssum = 0.0, qsum = 0.0;
+            for (int hh = 0; hh < H; ++hh) {
+                ssum += __hip_atomic_load(p + 2 * hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                qsum += __hip_atomic_load(p + 2 * hh + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ch = ssum / (double)H;
+            q2 = qsum;
+        }
+    }
+    if (last && sl == 0) {
+        const float q = (float)sqrt(q2) * (1.0f / sqrtf((float)H));
+        if (a.rp_side == 1) {
+            a.rp_sgt[nr] = own ? ch : -INFINITY;
+            a.rp_band[nr] = q * (1.0f + a.rp_unit) * 1.0001f + a.rp_cacc;
+            a.rp_count[nr] = 0;
+        } else {
+            a.rp_band[nr] = q * 1.0001f;
+        }
+    }
     if (a.rp_side != 1) return;
     if (blockIdx.x == 0 && threadIdx.x < 4) a.rp_pairs[threadIdx.x] = 0u;
     const int nblk = (a.rp_Nv + 63) >> 6;
@@ -350,7 +392,7 @@ __global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
             if (a.E16) store16x4(a.E16, item * d + col, g[j], a.e16_scale, a.e16_bf16);
         }
     }
-    if (a.rp_side) rank_side<NCH>(a, n, lane, g);                  // kernel-uniform
+    if (a.rp_side) rank_side<NCH>(a, n, h, lane, g);               // kernel-uniform
 }
 
 // ---- streaming variant: any d % 4 == 0 (planes re-read from L2; used for d > 512) -----------------------------

@@ -117,7 +117,7 @@ struct FuseArgs {
     void* E16;            // optional [N, H*d] 16-bit GEMM operand (E * e16_scale), fp16 or bf16
     int e16_bf16;
     float e16_scale;
-    // laff_rank_prepare's work for these rows done by this launch (laff_fuse_packed_rank; H == 1, d <= 512, E16 given): the wave
+    // laff_rank_prepare's work for these rows done by this launch (laff_fuse_packed_rank; heads of d <= 512, E16 given): the wave
     // that has just produced a row measures its operand's rounding error (band) and, on the text side, scores it exactly against its
     // ground-truth video (s_gt64) -- the rows are not read back by a separate launch.  rp_side 0 = off, 1 = text rows, 2 = video rows.
     int rp_side;
@@ -130,6 +130,8 @@ struct FuseArgs {
     float* rp_band_v;         // side 1: the partner's band_v
     int* rp_count;            // side 1: [N], cleared
     unsigned* rp_pairs;       // side 1: pair-list header, cleared
+    double* rp_part;          // H > 1: [N][H][2] scratch {head term of the exact score, q_h^2}
+    unsigned* rp_ticket;      // H > 1: [N] arrival counters, zero at launch
     float rp_unit, rp_cacc;   // unit roundoff of the operand format, accumulation term of the band (see launch_rank_prepare)
 };
 hipError_t launch_fuse(const FuseArgs& a, hipStream_t st);

@@ -67,11 +67,16 @@ class HipBackend:
             return None
         d = getattr(tl, 'head_dim', None) or getattr(tl, 'embed_dim', None)
         dv = getattr(vl, 'head_dim', None) or getattr(vl, 'embed_dim', None)
-        if d is None or d != dv or getattr(tl, 'multi_heads', 1) != 1 or getattr(vl, 'multi_heads', 1) != 1:
+        if d is None or d != dv or getattr(tl, 'multi_heads', 1) != heads or getattr(vl, 'multi_heads', 1) != heads:
+            return None
+        if heads > 1:
+            # laff_fuse_packed_rank covers several heads (the heads of a row meet through a scratch + arrival tickets, s_gt64 stays
+            # bit-equal), but there it costs what it saves: C1 (8 heads) fuse 1.40 -> 1.75 ms for a 0.33 ms rank_prepare launch, C5
+            # 2.03 -> 2.95 for 0.86 -- the separate launch stays
             return None
         if not ops.fused_prepare_eligible(Nt, Nv, heads, int(d), self.precision):
             return None
-        return ops.FusedPrepare(Nt, Nv, gt, col0)
+        return ops.FusedPrepare(Nt, Nv, gt, col0, heads=heads)
 
     def txt_layer(self):
         return self.model.txt_net.attention_layer

@@ -146,7 +146,7 @@ class Multi_head_MyApply_Attention(nn.Module):
         flags = ops.attention_flags(self.with_ave, self.mul, self.l2norm_each_head, self.split_head)
         packed = getattr(self, 'emit_packed', None)       # 'fp16' | 'bf16': also emit the GEMM operand (last_packed)
         rec = getattr(self, 'record_weights', False) if record_weights is None else record_weights
-        side = getattr(self, 'rank_side', None) if (packed and self.multi_heads == 1) else None
+        side = getattr(self, 'rank_side', None) if packed else None
         res = ops.fuse(planes, self.multi_heads, self.head_dim, w, b, gw, flags, return_weights=rec, packed_precision=packed,
                        l2norm_planes=l2norm_planes, rank_side=side)
         res = res if isinstance(res, tuple) else (res,)

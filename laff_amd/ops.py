@@ -599,9 +599,9 @@ def default_pair_cap(Nt):
 
 
 def fused_prepare_eligible(Nt, Nv, H, d, precision):
-    """laff_fuse_packed_rank covers one head of d <= 512 with a single-plane 16-bit operand; the text launch finishes the videos'
-    64-column block maxima (16 Nt >= Nv)."""
-    return H == 1 and d <= 512 and d % 4 == 0 and precision in ('fp16', 'bf16') and Nv >= 1 and 16 * Nt >= Nv
+    """laff_fuse_packed_rank covers split heads of d <= 512 with a single-plane 16-bit operand; the text launch finishes the videos'
+    64-column block maxima (it needs ceil(Nv / 64) workgroups of 4 (row, head) items)."""
+    return H >= 1 and d <= 512 and d % 4 == 0 and precision in ('fp16', 'bf16') and Nv >= 1 and 16 * Nt * H >= Nv * 4 and 16 * Nt >= Nv
 
 
 class FusedPrepare:
@@ -615,14 +615,23 @@ class FusedPrepare:
 
         def side_struct(self, N, E):
             o = self.owner
+            H = E.shape[1]
+            if H != o.heads:
+                raise ValueError('the tower produced %d heads, FusedPrepare was made for %d' % (H, o.heads))
+            part = tick = None
+            if H > 1:
+                part = torch.empty((N, H, 2), device=E.device, dtype=torch.float64)
+                tick = torch.empty((N,), device=E.device, dtype=torch.int32)
+                o._scratch.append((part, tick))
+            pp, tp = (part.data_ptr() if part is not None else None), (tick.data_ptr() if tick is not None else None)
             if self.side == 2:
                 if N != o.Nv:
                     raise ValueError('the video tower produced %d rows, FusedPrepare was made for %d' % (N, o.Nv))
-                return RankSide(2, None, 0, None, 0, None, o.band_v.data_ptr(), None, None, None)
+                return RankSide(2, None, 0, None, 0, None, o.band_v.data_ptr(), None, None, None, pp, tp)
             if N != o.Nt or o.Ev is None:
                 raise ValueError('the text tower must run behind the video tower (%d rows, FusedPrepare made for %d)' % (N, o.Nt))
             return RankSide(1, o.gt_col.data_ptr(), o.col0, o.Ev.data_ptr(), o.Nv, o.s_gt64.data_ptr(), o.band_t.data_ptr(),
-                            o.band_v.data_ptr(), o.count.data_ptr(), o.pairs.data_ptr())
+                            o.band_v.data_ptr(), o.count.data_ptr(), o.pairs.data_ptr(), pp, tp)
 
         def done(self, E, packed):
             if self.side == 2:
@@ -630,7 +639,7 @@ class FusedPrepare:
             else:
                 self.owner.Et, self.owner.T = E, packed
 
-    def __init__(self, Nt, Nv, gt_col, col0=0, pair_cap=None):
+    def __init__(self, Nt, Nv, gt_col, col0=0, pair_cap=None, heads=1):
         _dev(gt_col, 'gt_col', torch.int32)
         if gt_col.numel() != Nt or not gt_col.is_contiguous():
             raise ValueError('gt_col must be a contiguous int32 vector of %d' % Nt)
@@ -640,19 +649,20 @@ class FusedPrepare:
         cap = (int(pair_cap) if pair_cap is not None else default_pair_cap(Nt)) & ~3
         if cap < 4:
             raise ValueError('pair_cap must be >= 4')
-        self.Nt, self.Nv, self.gt_col, self.col0, self.pair_cap = Nt, Nv, gt_col, int(col0), cap
+        self.Nt, self.Nv, self.gt_col, self.col0, self.pair_cap, self.heads = Nt, Nv, gt_col, int(col0), cap, int(heads)
         self.s_gt64 = torch.empty((Nt + 2,), device=dev, dtype=torch.float64)[:Nt]
         self.band_t = torch.empty((Nt + 4,), device=dev, dtype=torch.float32)
         self.band_v = torch.empty((((Nv + 3) & ~3) + (Nv + 63) // 64 + 4,), device=dev, dtype=torch.float32)
         self.count = torch.empty((Nt,), device=dev, dtype=torch.int32)
         self.pairs = torch.empty((4 + 2 * cap,), device=dev, dtype=torch.int32)
         self.Et = self.Ev = self.T = self.V = None
+        self._scratch = []
         self.video, self.text = self._Side(self, 2), self._Side(self, 1)
 
     def state(self):
         if self.Et is None or self.Ev is None:
             raise RuntimeError('FusedPrepare.state(): both fuse launches must have run (videos first)')
-        return RankState(self.Et, self.Ev, self.T, self.V, 1, self.gt_col, self.col0, self.s_gt64, self.band_t, self.band_v,
+        return RankState(self.Et, self.Ev, self.T, self.V, self.heads, self.gt_col, self.col0, self.s_gt64, self.band_t, self.band_v,
                          self.count, self.pairs, self.pair_cap)
 
 

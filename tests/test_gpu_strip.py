@@ -265,29 +265,29 @@ def test_strip_kernel_on_video_shards(strip_mode):
     assert torch.equal(total, want)
 
 
-@pytest.mark.parametrize('prec', ['fp16', 'bf16'])
-def test_fused_prepare_leaves_what_rank_prepare_leaves(prec):
+@pytest.mark.parametrize('prec,H,d', [('fp16', 1, 512), ('bf16', 1, 512), ('fp16', 8, 128), ('bf16', 2, 512), ('fp16', 3, 260)])
+def test_fused_prepare_leaves_what_rank_prepare_leaves(prec, H, d):
     """laff_fuse_packed_rank: the two fuse launches of a pass (videos first) do laff_rank_prepare's work -- s_gt64 BIT-equal (same
-    arithmetic as the re-score), bands equal to rounding (never narrower than 1 - 1e-6 of rank_prepare's), count / list header cleared
-    -- and the pipeline that follows gives the float64 ranks."""
+    arithmetic as the re-score, also with the heads of a row coming from different workgroups), bands equal to rounding (never
+    narrower than 1 - 1e-6 of rank_prepare's), count / list header cleared -- and the pipeline that follows gives the float64 ranks."""
     from laff_amd import ops
-    Nt, Nv, d, L = 6000, 2100, 512, 3
+    Nt, Nv, L = 6001, 2103, 3
     g = torch.Generator(device=DEV).manual_seed(5)
     z = torch.randn(Nv, 32, generator=g, device=DEV)
     gt = (torch.arange(Nt, device=DEV) * 31 % Nv).to(torch.int32)
-    w = torch.randn(1, d, generator=g, device=DEV) * 0.05
-    b, gw = torch.zeros(1, device=DEV), torch.ones(1, device=DEV)
+    w = torch.randn(H, d, generator=g, device=DEV) * 0.05
+    b, gw = torch.zeros(H, device=DEV), torch.ones(H, device=DEV)
 
     def planes(n, lat):
-        return [(lat @ torch.randn(32, d, generator=g, device=DEV) + 3.0 * torch.randn(n, d, generator=g, device=DEV), False, None, None)
+        return [(lat @ torch.randn(32, H * d, generator=g, device=DEV) + 3.0 * torch.randn(n, H * d, generator=g, device=DEV), False, None, None)
                 for _ in range(L)]
     pv, pt = planes(Nv, z), planes(Nt, z[gt.long()])
     flags = ops.attention_flags(True, False)
-    fp = ops.FusedPrepare(Nt, Nv, gt)
+    fp = ops.FusedPrepare(Nt, Nv, gt, heads=H)
     fp.count.fill_(7)
     fp.pairs[:4] = 9
-    Ev, V = ops.fuse(pv, 1, d, w, b, gw, flags, packed_precision=prec, rank_side=fp.video)
-    Et, T = ops.fuse(pt, 1, d, w, b, gw, flags, packed_precision=prec, rank_side=fp.text)
+    Ev, V = ops.fuse(pv, H, d, w, b, gw, flags, packed_precision=prec, rank_side=fp.video)
+    Et, T = ops.fuse(pt, H, d, w, b, gw, flags, packed_precision=prec, rank_side=fp.text)
     st = fp.state()
     ref = ops.rank_prepare(Et, Ev, T, V, gt)
     assert torch.equal(st.s_gt64, ref.s_gt64)
@@ -300,8 +300,8 @@ def test_fused_prepare_leaves_what_rank_prepare_leaves(prec):
     assert not st.listed_pairs()[1]
     assert torch.equal(st.count, _fp64_count(Et, Ev, gt))
     # a text whose video is not among these columns: -inf, like rank_prepare
-    fp2 = ops.FusedPrepare(Nt, Nv, gt, col0=100)
-    ops.fuse(pv, 1, d, w, b, gw, flags, packed_precision=prec, rank_side=fp2.video)
-    ops.fuse(pt, 1, d, w, b, gw, flags, packed_precision=prec, rank_side=fp2.text)
+    fp2 = ops.FusedPrepare(Nt, Nv, gt, col0=100, heads=H)
+    ops.fuse(pv, H, d, w, b, gw, flags, packed_precision=prec, rank_side=fp2.video)
+    ops.fuse(pt, H, d, w, b, gw, flags, packed_precision=prec, rank_side=fp2.text)
     out = (gt < 100) | (gt >= 100 + Nv)
     assert bool(torch.isneginf(fp2.s_gt64[out]).all()) and bool(torch.isfinite(fp2.s_gt64[~out]).all())
