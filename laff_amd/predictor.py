@@ -19,7 +19,7 @@ def gt_columns(txt_ids, vis_ids):
             raise ValueError("video id '%s' appears twice in vis_ids" % v)
         index[v] = i
     try:
-        return np.fromiter((index[t.split('#')[0]] for t in txt_ids), dtype=np.int32, count=len(txt_ids))
+        return np.fromiter((index[t.partition('#')[0]] for t in txt_ids), dtype=np.int32, count=len(txt_ids))      # (= t.split('#')[0], half the time)
     except KeyError as e:
         raise IndexError('caption refers to a video that is not in vis_ids: %s' % e)   # reference: gt_index[0] fails
 
