@@ -57,8 +57,8 @@ constexpr int STAGE = CB * KBYTES;             // one ring slot: 32 KiB
 constexpr int RING = 3;                        // ring slots: block b lives in slot b % 3
 constexpr int PIECES = CB / 4;                 // 1 KiB LDS-DMA pieces (= columns) per wave per block
 constexpr int SLAB_OFF = RING * STAGE;         // per-wave fp32 transpose slabs, one per job (32 rows x 32 columns) of a column block:
-constexpr int SLAB_JOB = 32 * 128;             // 128-byte rows, 16-byte chunk c of row r at position c ^ ((r >> 1) & 3) -- conflict-free for
-constexpr int SLAB_BYTES = 2 * SLAB_JOB;       // the quad-column ds_write_b128 (8 rows at a time) and the row-wise ds_read_b128 (a row per 8 lanes)
+constexpr int SLAB_JOB = 32 * 128;             // 128-byte rows, 16-byte chunk c of row r at position c ^ (r & 7) -- conflict-free for the
+constexpr int SLAB_BYTES = 2 * SLAB_JOB;       // quad-column ds_write_b128 (8 rows at a time, banks = dword mod 32) and the row-wise ds_read_b128
 constexpr int BAND_OFF = SLAB_OFF + 4 * SLAB_BYTES;       // band maximum of every aligned group of 64 columns (fp32)
 constexpr int DUMP_OFF = BAND_OFF + STRIP_MAX_GROUPS * 4;  // per-wave staging of one chunk of dumped groups (STRIP_CHUNK entries)
 constexpr int DUMP_BYTES = STRIP_CHUNK * STRIP_ENTRY_WORDS * 4;
@@ -401,13 +401,17 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
     const unsigned m0_keep = m0_get();
     // slab addresses of this wave: written in accumulator layout (row l31, 4 consecutive columns per quad), read back as rows
     const unsigned slab0 = lds0 + SLAB_OFF + (unsigned)wave * SLAB_BYTES;
-    // lane (l31, hh) holds of text row l31 the column quads 2 q + hh (q = e >> 2): chunk position (2 q + hh) ^ k, k = (l31 >> 1) & 3
-    // = (q >> 1) * 64 bytes + [q & 1]
-    const unsigned slab_k = (unsigned)(l31 >> 1) & 3u;
-    const unsigned slab_w0 = slab0 + (unsigned)l31 * 128u + ((((slab_k >> 1) << 1) | ((unsigned)hh ^ (slab_k & 1u))) << 4);     // q & 1 == 0
-    const unsigned slab_w1 = slab_w0 ^ 32u;                                                                                  // q & 1 == 1
-    // read-back i: rows 8 i .. 8 i + 7, a whole 128-byte row per 8 lanes ((r >> 1) & 3 of row 8 i + (lane >> 3) is (lane >> 4) & 3)
-    const unsigned slab_r = slab0 + (unsigned)(lane >> 3) * 128u + (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4);
+    // lane (l31, hh) holds of text row l31 the column quads 2 q + hh (q = e >> 2): chunk position (2 q + hh) ^ k, k = l31 & 7 -- the 8
+    // rows a ds_write_b128 stores in one LDS cycle (lanes 8 g .. 8 g + 7; its banks are dword mod 32 = one 128-byte row) then take 8
+    // different positions.  (With k = (l31 >> 1) & 3, chosen for 256-byte banking, every such store was a 2-way conflict: 12.6M of 61M
+    // LDS cycles per launch at C4, SQ_LDS_BANK_CONFLICT.)
+    const unsigned slab_k = (unsigned)l31 & 7u;
+    unsigned slab_w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) slab_w[q] = slab0 + (unsigned)l31 * 128u + ((((unsigned)(2 * q + hh)) ^ slab_k) << 4);
+    // read-back i: rows 8 i .. 8 i + 7, a whole 128-byte row per 8 lanes (row & 7 = lane >> 3); the 16 lanes a ds_read_b128 serves per
+    // cycle ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md) take half rows of four rows, two per 128-byte half of the banks: no conflict
+    const unsigned slab_r = slab0 + (unsigned)(lane >> 3) * 128u + (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
     const unsigned wrow = (unsigned)(PIECES * wave) * KBYTES;              // this wave's 8 columns of a block (LDS and source offset)
 
 #ifndef LAFF_STRIP_SERIAL
@@ -660,11 +664,11 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                 // quad (two in turn: the LDS store is still reading its data registers when the next quad's first product is issued
                 // right behind it, and nothing interlocks an asm store's sources against an asm VALU write).  scale == 1 (one head, bf16
                 // or un-prescaled fp16 operands): the accumulator quad goes to the slab as it is.
-                const unsigned wa = (arg & 1) ? slab_w1 : slab_w0;
+                const unsigned wa = slab_w[arg];
                 const f32x16& x = acc[Q][rb];
                 if constexpr (SCALE1) {
                     const f32x4 q4 = {x[4 * arg], x[4 * arg + 1], x[4 * arg + 2], x[4 * arg + 3]};
-                    lds_write128<(arg >> 1) * 64 + rb * SLAB_JOB>(wa, q4);
+                    lds_write128<rb * SLAB_JOB>(wa, q4);
                 } else {
                     // (fixed scratch registers named as clobbers: an asm operand cannot address the elements of a register quad)
                     const float sc = scale;
@@ -672,12 +676,12 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                         asm volatile("v_mul_f32 v248, %5, %0\n\tv_mul_f32 v249, %5, %1\n\tv_mul_f32 v250, %5, %2\n\tv_mul_f32 v251, %5, %3\n\t"
                                      "ds_write_b128 %4, v[248:251] offset:%6"
                                      :: "v"(x[4 * arg]), "v"(x[4 * arg + 1]), "v"(x[4 * arg + 2]), "v"(x[4 * arg + 3]), "v"(wa), "s"(sc),
-                                        "n"((arg >> 1) * 64 + rb * SLAB_JOB) : "v248", "v249", "v250", "v251", "memory");
+                                        "n"(rb * SLAB_JOB) : "v248", "v249", "v250", "v251", "memory");
                     else
                         asm volatile("v_mul_f32 v252, %5, %0\n\tv_mul_f32 v253, %5, %1\n\tv_mul_f32 v254, %5, %2\n\tv_mul_f32 v255, %5, %3\n\t"
                                      "ds_write_b128 %4, v[252:255] offset:%6"
                                      :: "v"(x[4 * arg]), "v"(x[4 * arg + 1]), "v"(x[4 * arg + 2]), "v"(x[4 * arg + 3]), "v"(wa), "s"(sc),
-                                        "n"((arg >> 1) * 64 + rb * SLAB_JOB) : "v252", "v253", "v254", "v255", "memory");
+                                        "n"(rb * SLAB_JOB) : "v252", "v253", "v254", "v255", "memory");
                 }
             } else if constexpr (op.kind == OP_CHK) {
                 // ONE test per block for both jobs (a ballot + scalar branch costs a lone wave ~60 cycles: 4 % of the launch as one per
