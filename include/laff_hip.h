@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 15
+#define LAFF_ABI_VERSION 16
 
 enum {
     LAFF_OK = 0,
@@ -126,6 +126,24 @@ typedef struct {
     float* Y; int ldy;
 } laff_fc_fused_problem;
 int laff_fc_act_bn_fused_grouped(laff_ctx* ctx, const laff_fc_fused_problem* problems /*host array*/, int count);
+
+/* a1 / a3 in STRIP form for Dk == 512 inputs (TransformNet.forward, model/model.py:257-276; the per-feature loops :1807-1827 and
+ * :1673-1681): same arithmetic as the fused-split form above (fp16 hi/lo, three products, fp32 accumulation) with X STATIONARY --
+ * a wavefront loads 32 fp32 input rows once, finds their maxima and converts them to hi / lo MFMA fragments in registers (no
+ * laff_row_scales_grouped pass, nothing of the split ever in memory); W streams through LDS from an image packed once per model:
+ *   laff_fc_strip_pack(W[D,512], bias, bn_scale, bn_shift, act) -> img  (laff_fc_strip_pack_bytes(D) bytes, 16-byte aligned: the hi/lo
+ *   fragments of W in LDS order + the per-column epilogue constants with bias, activation and folded BatchNorm pre-combined)
+ * Needs Dk == 512, D % 32 == 0, ldx % 4 == 0, 16-byte aligned X; any N, any ldy >= D.  Up to 8 problems per launch; problems of
+ * different D or activation kind are launched separately.  |Y - fp64| as the other fp16x3 forms (<= ~1e-6 of the row / weight scale). */
+int laff_fc_strip_pack_bytes(int D, int Dk, size_t* out);
+int laff_fc_strip_pack(laff_ctx* ctx, const float* W, int ldw, const float* bias, const float* bn_scale, const float* bn_shift, int D,
+                       int Dk, int act, void* img);
+typedef struct {
+    const float* X; int ldx; int N;
+    const void* img; int D, act;                                /* laff_fc_strip_pack(...) of this feature's TransformNet */
+    float* Y; int ldy;
+} laff_fc_strip_problem;
+int laff_fc_act_bn_strip_grouped(laff_ctx* ctx, const laff_fc_strip_problem* problems /*host array*/, int count);
 
 /* a1 for a SPARSE input feature (bag-of-words, model/model.py:399-416): X given as CSR (indptr[N+1], indices[nnz],
  * values[nnz] or NULL = all ones) over Dk columns; Wt = W^T [Dk, ldwt >= D] so that one vocabulary entry is one contiguous

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get('LAFF_HIP_LIB') or os.path.join(_HERE, 'lib', 'liblaff
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class Plane(C.Structure):
@@ -28,6 +28,11 @@ class FcFusedProblem(C.Structure):
     _fields_ = [('X', C.c_void_p), ('ldx', C.c_int), ('x_rscale', C.c_void_p), ('N', C.c_int), ('Dk', C.c_int),
                 ('Ws', C.c_void_p), ('w_rscale', C.c_void_p), ('bias', C.c_void_p), ('bn_scale', C.c_void_p),
                 ('bn_shift', C.c_void_p), ('D', C.c_int), ('act', C.c_int), ('Y', C.c_void_p), ('ldy', C.c_int)]
+
+
+class FcStripProblem(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('ldx', C.c_int), ('N', C.c_int), ('img', C.c_void_p), ('D', C.c_int), ('act', C.c_int),
+                ('Y', C.c_void_p), ('ldy', C.c_int)]
 
 
 class FcProblem(C.Structure):
@@ -58,6 +63,9 @@ SIGNATURES = {
     'laff_row_scales_grouped': (C.c_int, [_P, _I, C.POINTER(C.c_void_p), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I),
                                           C.POINTER(C.c_void_p)]),
     'laff_fc_act_bn_fused_grouped': (C.c_int, [_P, C.POINTER(FcFusedProblem), _I]),
+    'laff_fc_strip_pack_bytes': (C.c_int, [_I, _I, C.POINTER(C.c_size_t)]),
+    'laff_fc_strip_pack': (C.c_int, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    'laff_fc_act_bn_strip_grouped': (C.c_int, [_P, C.POINTER(FcStripProblem), _I]),
     'laff_frame_fuse_grouped': (C.c_int, [_P, _I, C.POINTER(C.c_void_p), _P, _I, _I, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.c_uint, C.POINTER(C.c_void_p)]),
     'laff_split_rows_bytes': (C.c_int, [_I, _I, C.POINTER(C.c_size_t)]),

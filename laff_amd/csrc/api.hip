@@ -80,6 +80,7 @@ int laff_ctx_create(int device, void* hip_stream, laff_ctx** out) {
     if (const char* e = getenv("LAFF_GEMM_VARIANT")) laff::g_gemm_variant = atoi(e);
     if (const char* e = getenv("LAFF_STRIP")) laff::g_strip_mode = atoi(e);
     if (const char* e = getenv("LAFF_STRIP_MAP")) laff::g_strip_map = atoi(e);
+    if (const char* e = getenv("LAFF_FC_STRIP")) laff::g_fc_strip = atoi(e);
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(LAFF_E_ARG, "laff_ctx_create: device %d out of range (%d devices)", device, n);
@@ -397,6 +398,65 @@ int laff_fc_act_bn_fused_grouped(laff_ctx* ctx, const laff_fc_fused_problem* pro
         }
     }
     if (ga.count) HIP_TRY(laff::launch_gemm_nt_x3_fused_grouped(ga, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_fc_strip_pack_bytes(int D, int Dk, size_t* out) {
+    if (!out || D < 32 || (D & 31)) return fail(LAFF_E_SHAPE, "laff_fc_strip_pack_bytes: D must be a positive multiple of 32 (D=%d)", D);
+    if (Dk != laff::FC_STRIP_K) return fail(LAFF_E_SHAPE, "laff_fc_strip_pack_bytes: the strip form takes Dk == 512 (Dk=%d)", Dk);
+    *out = laff::fc_strip_image_bytes(D);
+    return LAFF_OK;
+}
+
+int laff_fc_strip_pack(laff_ctx* ctx, const float* W, int ldw, const float* bias, const float* bn_scale, const float* bn_shift, int D,
+                       int Dk, int act, void* img) {
+    CHECK_CTX(ctx);
+    if (!W || !img) return fail(LAFF_E_ARG, "laff_fc_strip_pack: null W / img");
+    if (D < 32 || (D & 31) || Dk != laff::FC_STRIP_K || ldw < Dk)
+        return fail(LAFF_E_SHAPE, "laff_fc_strip_pack: need D %% 32 == 0, Dk == 512, ldw >= Dk (D=%d Dk=%d ldw=%d)", D, Dk, ldw);
+    if ((long long)D * 2048 >= (1ll << 32)) return fail(LAFF_E_UNSUPPORTED, "laff_fc_strip_pack: image exceeds 4 GiB");
+    if (act < LAFF_ACT_NONE || act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fc_strip_pack: bad act %d", act);
+    if ((bn_scale == nullptr) != (bn_shift == nullptr)) return fail(LAFF_E_ARG, "laff_fc_strip_pack: bn_scale/bn_shift must come together");
+    if (!aligned16(img)) return fail(LAFF_E_ALIGN, "laff_fc_strip_pack: img must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_fc_strip_pack(W, ldw, bias, bn_scale, bn_shift, D, act, img, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_fc_act_bn_strip_grouped(laff_ctx* ctx, const laff_fc_strip_problem* problems, int count) {
+    CHECK_CTX(ctx);
+    if (!problems || count < 0) return fail(LAFF_E_ARG, "laff_fc_act_bn_strip_grouped: bad problem list");
+    DeviceGuard g(ctx->device);
+    auto kind = [](int act) { return act == LAFF_ACT_TANH || act == LAFF_ACT_SIGMOID ? 2 : (act == LAFF_ACT_RELU ? 1 : 0); };
+    std::vector<char> done((size_t)count, 0);
+    for (int i = 0; i < count; ++i) {
+        const laff_fc_strip_problem& q = problems[i];
+        if (q.N == 0) { done[i] = 1; continue; }
+        if (!q.X || !q.img || !q.Y) return fail(LAFF_E_ARG, "laff_fc_act_bn_strip_grouped: problem %d has a null operand", i);
+        if (q.N < 0 || q.D < 32 || (q.D & 31) || q.ldy < q.D || q.ldx < laff::FC_STRIP_K || (q.ldx & 3))
+            return fail(LAFF_E_SHAPE, "laff_fc_act_bn_strip_grouped: problem %d: need D %% 32 == 0, ldx >= 512, ldx %% 4 == 0 (N=%d D=%d ldx=%d ldy=%d)",
+                        i, q.N, q.D, q.ldx, q.ldy);
+        if (q.act < LAFF_ACT_NONE || q.act > LAFF_ACT_SIGMOID) return fail(LAFF_E_ARG, "laff_fc_act_bn_strip_grouped: bad act %d", q.act);
+        if (!aligned16(q.X) || !aligned16(q.img)) return fail(LAFF_E_ALIGN, "laff_fc_act_bn_strip_grouped: problem %d: 16-byte alignment", i);
+        if ((long long)laff::FC_STRIP_ROWS * q.ldy * 4 >= (1ll << 31) || (long long)q.D * 2048 >= (1ll << 32))
+            return fail(LAFF_E_UNSUPPORTED, "laff_fc_act_bn_strip_grouped: problem %d: output strip / image exceeds the 32-bit buffer range", i);
+    }
+    // one launch per (D, activation kind), up to MAX_GROUP problems each
+    for (int i = 0; i < count; ++i) {
+        if (done[i]) continue;
+        laff::FcStripArgs fa{};
+        fa.nblk = problems[i].D / 32;
+        const int k = kind(problems[i].act);
+        for (int j = i; j < count && fa.count < laff::MAX_GROUP; ++j) {
+            const laff_fc_strip_problem& q = problems[j];
+            if (done[j] || q.D != problems[i].D || kind(q.act) != k) continue;
+            laff::FcStripProblem& fp = fa.p[fa.count++];
+            fp.X = q.X; fp.img = q.img; fp.vec = (const float*)((const char*)q.img + laff::fc_strip_vec_offset(q.D));
+            fp.Y = q.Y; fp.ldx = q.ldx; fp.ldy = q.ldy; fp.N = q.N;
+            done[j] = 1;
+        }
+        HIP_TRY(laff::launch_fc_strip(fa, problems[i].act, ctx->stream));
+    }
     return LAFF_OK;
 }
 

@@ -1,0 +1,544 @@
+// fc_strip.hip -- TransformNet.forward (FC -> activation -> folded BatchNorm; /root/reference/model/model.py:257-276) for K = 512 inputs
+// as a STRIP kernel for gfx950, X stationary:
+//
+//   Y[r][c] = bn_s[c] * act( sum_k X[r][k] W[c][k] + bias[c] ) + bn_t[c]          fp32 in / fp32 out, fp32-class accuracy
+//
+// on the fp16 matrix pipe: X = s_r (Xhi + Xlo), W = s_c (Whi + Wlo) with power-of-two scales (row maximum scaled into [512, 1024)), the
+// three products lo*hi + hi*lo + hi*hi accumulate in fp32 (fp16 x fp16 products are exact in fp32), the epilogue undoes the scales.
+//
+// The tiled kernel this replaces (gemm_nt.hip, gemm_tile_x3 with the input split fused) ran at 39 % MFMA utilisation and needed a separate
+// pass over the inputs for the row scales.  Here:
+//   * a workgroup is 4 wavefronts, ONE PER SIMD, 512 registers each.  A wavefront owns 32 input rows: it loads them ONCE (fp32, straight
+//     into the accumulator half of the register file), finds the row maxima there (a row lives in two lanes), and converts them in
+//     place into the MFMA A fragments of hi and lo for the WHOLE K = 512 (2 x 128 registers).  No row-scale launch, no split planes
+//     in memory, the conversion happens once per row -- not once per column tile;
+//   * only W moves: it is packed once per model (laff_fc_strip_pack) into an LDS image -- per block of 32 output columns and half of
+//     K one 32 KiB ring slot {hi plane, lo plane} x 16 sub-steps x 64 lanes x 16 bytes, i.e. exactly the ds_read_b128 fragment
+//     order -- so the LDS-DMA is a linear copy and a fragment read is lane-linear (conflict-free by construction).  W of a feature is
+//     1 MiB: it streams from L2;
+//   * per sub-step (16 k) two fragment reads feed three MFMAs 32x32x16 (Xlo.Whi, Xhi.Wlo, Xhi.Whi);
+//   * MFMA roles: A = X rows, B = W columns, so a lane's accumulators are 16 ROWS of ONE output column: the per-column epilogue
+//     parameters are four lane constants per block, and a store instruction (dword per lane) writes 2 rows x 128 contiguous bytes --
+//     whole cache lines without a transposing slab;
+//   * two accumulator sets alternate: the epilogue of block b - 1 (scale, bias, tanh on v_exp/v_rcp, BatchNorm, store) is issued in
+//     the shadow of block b's MFMAs, a few instructions behind each one, at places computed at compile time (make_plan) together
+//     with the operands of the counted s_waitcnt;
+//   * persistent grid: the (feature, strip, column block) units of ALL problems of a launch are cut into equal contiguous ranges.
+//
+// The k index inside a sub-step is permuted (any bijection is legal as long as A and B agree): lane (i, hh) element e holds
+// k = 16 j + 4 hh + (e & 3) + 8 (e >> 2), so that the strip load's 16-byte pieces of lanes hh = 0, 1 are adjacent in the row.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "kernels.h"
+#include "strip_util.h"
+
+namespace laff {
+
+namespace {
+
+using namespace su;
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+constexpr int FR = FC_STRIP_ROWS;              // 128 rows per strip: 4 wavefronts x 32
+constexpr int SLOT = 32 * 1024;                // one ring slot: 32 columns x 256 k x {hi, lo}
+constexpr int PLANE = 16 * 1024;
+constexpr int RING = 4;
+constexpr int PIECES = 8;                      // 1 KiB LDS-DMA pieces per wave per slot
+constexpr int RS_OFF = RING * SLOT;            // per wave: 32 row scales (fp32)
+constexpr int SMEM = RS_OFF + 4 * 128;
+static_assert(SMEM <= 160 * 1024, "LDS budget");
+
+constexpr int FD = 6;                          // fragment reads run FD sub-steps ahead, 8 register sets
+constexpr int BAR_J = 16 - FD;                 // the body's barrier sits in front of this sub-step
+constexpr int NSLOT = 96;                      // MFMA issue slots of a column block: 2 bodies x 16 sub-steps x 3
+
+// ---- all 256 accumulator registers are named literally (the strip): nothing else lives there ---------------------------------------
+#define A16(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define AGPR_ALL                                                                                                                   \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", A16(1), A16(2), A16(3), A16(4), A16(5), A16(6), A16(7), A16(8), A16(9), \
+        A16(10), A16(11), A16(12), A16(13), A16(14), A16(15), A16(16), A16(17), A16(18), A16(19), A16(20), A16(21), A16(22), A16(23), \
+        A16(24), "a250", "a251", "a252", "a253", "a254", "a255"
+__device__ __forceinline__ void agpr_claim() { asm volatile("" ::: AGPR_ALL); }
+
+template <int R, int OFF>
+__device__ __forceinline__ void agpr_load4(const void* p) {            // a[R .. R + 3] <- 16 bytes at p + OFF
+    asm volatile("global_load_dwordx4 a[%c1:%c2], %0, off offset:%c3" ::"v"(p), "n"(R), "n"(R + 3), "n"(OFF) : "memory");
+}
+template <int R>
+__device__ __forceinline__ float agpr_read() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "n"(R));
+    return x;
+}
+template <int R>
+__device__ __forceinline__ void agpr_write(unsigned x) { asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(x), "n"(R)); }
+
+// acc (+)= A(strip fragment in a[R .. R + 3]: rows of X) x B(fragment of the W stream: output columns)
+template <int R, bool FIRST>
+__device__ __forceinline__ void mfma_strip(f32x16& acc, const u32x4& wfrag) {
+    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, a[%c2:%c3], %1, 0" : "=v"(acc) : "v"(wfrag), "n"(R), "n"(R + 3));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, a[%c2:%c3], %1, %0" : "+v"(acc) : "v"(wfrag), "n"(R), "n"(R + 3));
+}
+
+template <int IMM>
+__device__ __forceinline__ void lds_read128(u32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(IMM));
+}
+
+// one 1 KiB piece of the W stream, straight into LDS (lane L lands at M0 base + 16 L; the image is already in LDS order)
+__device__ __forceinline__ void dma_piece(unsigned voff, u32x4 rsrc, unsigned soff, unsigned m0val) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(m0val) : "memory");
+}
+
+// row maximum -> exponent of the power-of-two scale: same rule as split_rows_kernel (fuse.hip): maximum scaled into [512, 1024)
+__device__ __forceinline__ int split_exponent(float m) {
+    const int be = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    if (!(m > 0.f) || be == 0xff) return 0;
+    return max(be - 127, -100);
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+
+// ---- the epilogue of a column block as a static stream of micro-ops -----------------------------------------------------------------
+// Per accumulator i (row 8 (i >> 2) + 4 hh + (i & 3) of the wave's 32, the lane's column):
+//   MUL t = acc * rs[i]   FMA1 t = t * c.x + c.y   [EXP t = 2^t   ADD1 t = t + 1   RCP t = 1 / t] | [MAX t = max(t, 0)]   FMA2 t = t * c.z + c.w   ST
+// with the lane constants c = {cs', b', c1, c0} folded by laff_fc_strip_pack so that the chain is the whole FC epilogue:
+//   tanh:    y' = 2 log2(e) (cs acc rs + bias), tanh = 1 - 2 / (2^y' + 1), out = (bn_s + bn_t) + (-2 bn_s) / (2^y' + 1)
+//   sigmoid: y' = -log2(e) (...),              out = bn_t + bn_s / (2^y' + 1)
+//   relu:    out = bn_s max(y, 0) + bn_t;      none: out = (cs bn_s) acc rs + (bn_s bias + bn_t)   (one fma)
+// Elements go in groups of four, stage by stage, so that a dependent pair is four instructions apart (the transcendental ->
+// VALU forwarding hazard needs one; hipcc pads nothing inside or between asm statements it cannot see into).
+enum : unsigned char { OP_WAITCV = 0, OP_MUL, OP_FMA1, OP_EXP, OP_ADD1, OP_RCP, OP_MAX, OP_FMA2, OP_ST };
+enum { ACT_LIN = 0, ACT_RELU = 1, ACT_EXP = 2 };                 // epilogue kinds (template parameter)
+struct EpiOp { unsigned char kind, elem; };
+struct EpiStream { EpiOp op[160]; int n; };
+constexpr int op_cost(unsigned char k) { return (k == OP_EXP || k == OP_RCP) ? 3 : (k == OP_WAITCV ? 0 : 1); }
+
+template <int ACTK>
+constexpr EpiStream make_stream() {
+    EpiStream s{};
+    s.n = 0;
+    auto push = [&](unsigned char k, int e) { s.op[s.n++] = EpiOp{k, (unsigned char)e}; };
+    push(OP_WAITCV, 0);
+    for (int g = 0; g < 4; ++g) {
+        auto stage = [&](unsigned char k) { for (int e = 0; e < 4; ++e) push(k, 4 * g + e); };
+        stage(OP_MUL);
+        stage(OP_FMA1);
+        if (ACTK == ACT_EXP) { stage(OP_EXP); stage(OP_ADD1); stage(OP_RCP); stage(OP_FMA2); }
+        if (ACTK == ACT_RELU) { stage(OP_MAX); stage(OP_FMA2); }
+        stage(OP_ST);
+    }
+    return s;
+}
+
+// ---- the schedule of one column block (two bodies H = 0, 1 of 16 sub-steps J, three MFMAs M each): slot sg = 48 H + 3 J + M ----------
+//   * (J, 0): the two fragment reads (hi, lo plane) of the sub-step FD ahead -- from J = BAR_J on that is the NEXT ring slot;
+//   * in front of sub-step BAR_J: counted vmcnt (this wave's pieces of the next slot have landed) + s_barrier (everybody's have, and
+//     everybody is done with the previous slot, which the pieces issued right behind the barrier refill -- 4 slots: 3 ahead);
+//   * (BAR_J .. BAR_J + 3, M = 1, 2): the 8 DMA pieces;  (H = 0, J = 0, M = 1): this block's four lane constants (one 16-byte load);
+//   * everything else: the epilogue stream of the previous block, spread evenly (cost-weighted).  It starts behind the third MFMA
+//     of the block (the previous block's last MFMA has retired by then) and ends before the block does.
+constexpr int slot_piece(int sg) {
+    const int J = (sg % 48) / 3, M = sg % 3;
+    if (M >= 1 && J >= BAR_J && J < BAR_J + 4) return 2 * (J - BAR_J) + (M - 1);
+    return -1;
+}
+constexpr bool slot_cvload(int sg) { return sg == 1; }
+struct Plan {
+    short begin[NSLOT + 1];
+    short vm_bar[2];      // vmcnt operand at the barrier of body H
+    short vm_cv;          // vmcnt operand in front of the first use of the previous block's lane constants
+    bool fits;
+};
+template <int ACTK>
+constexpr Plan make_plan() {
+    Plan p{};
+    const EpiStream st = make_stream<ACTK>();
+    int usable = 0, total = 0;
+    auto ok = [](int sg) { return sg >= 3 && slot_piece(sg) < 0; };
+    for (int sg = 0; sg < NSLOT; ++sg) usable += ok(sg) ? 1 : 0;
+    for (int i = 0; i < st.n; ++i) total += op_cost(st.op[i].kind);
+    usable -= 4;                                        // finish a few slots early
+    int at = 0, k = 0, spent = 0;
+    for (int sg = 0; sg < NSLOT; ++sg) {
+        p.begin[sg] = (short)at;
+        if (!ok(sg)) continue;
+        ++k;
+        const int target = (int)(((long)k * total + usable - 1) / usable);
+        while (at < st.n && spent < target) { spent += op_cost(st.op[at].kind); ++at; }
+    }
+    p.begin[NSLOT] = (short)at;
+    p.fits = at == st.n;
+    // vector-memory program order over three consecutive identical blocks; the third one is measured
+    int vm_n = 0, last_piece[3][2] = {}, cv_ord[3] = {}, bar_at[3][2] = {}, waitcv_at[3] = {};
+    for (int blk = 0; blk < 3; ++blk)
+        for (int sg = 0; sg < NSLOT; ++sg) {
+            const int H = sg / 48, J = (sg % 48) / 3, M = sg % 3;
+            if (J == BAR_J && M == 0) bar_at[blk][H] = vm_n;
+            if (slot_cvload(sg)) cv_ord[blk] = ++vm_n;
+            if (slot_piece(sg) >= 0) { ++vm_n; last_piece[blk][H] = vm_n; }
+            for (int i = p.begin[sg]; i < p.begin[sg + 1]; ++i) {
+                if (st.op[i].kind == OP_WAITCV) waitcv_at[blk] = vm_n;
+                if (st.op[i].kind == OP_ST) ++vm_n;
+            }
+        }
+    auto clamp = [](int c) { return c < 0 ? 0 : (c > 63 ? 63 : c); };
+    // barrier of body (b, H): the pieces of ring slot sigma + 1 were issued in body sigma - 2 = (b - 1, H)
+    for (int H = 0; H < 2; ++H) p.vm_bar[H] = (short)clamp(bar_at[2][H] - last_piece[1][H]);
+    p.vm_cv = (short)clamp(waitcv_at[2] - cv_ord[1]);
+    return p;
+}
+
+}  // namespace
+
+template <int ACTK>
+__global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    agpr_claim();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n31 = lane & 31, hh = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+
+    const int nblk = pin_s(a.nblk), count = pin_s(a.count);
+    const int nranges = pin_s(a.nranges);
+    const long U = (long)pin_s((unsigned)a.total_units);
+    const int myrange = a.range_of_wg[blockIdx.x];
+    long u0 = U * myrange / nranges;
+    const long u1 = U * (myrange + 1) / nranges;
+
+    constexpr Plan PLAN = make_plan<ACTK>();
+    constexpr EpiStream STREAM = make_stream<ACTK>();
+    static_assert(PLAN.fits, "the epilogue stream does not fit behind the MFMAs of one column block");
+
+    // per-lane constants of the loops
+    unsigned lane16 = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(lane16));
+    unsigned vP[PIECES];                                    // source offsets of the 8 pieces of a slot: piece P, lane L -> 1024 P + 16 L
+#pragma unroll
+    for (int P = 0; P < PIECES; ++P) { vP[P] = lane16 + 1024u * P; asm volatile("" : "+v"(vP[P])); }
+    const unsigned xa0 = lds0 + lane16, xa1 = lds0 + lane16 + 2u * SLOT;      // fragment addresses: ring slots 0, 1 | 2, 3
+    const unsigned wslot = (unsigned)wave * (PIECES * 1024u);                   // this wave's 8 KiB of a slot (LDS and source offset)
+    const unsigned m0_keep = m0_get();
+
+    while (u0 < u1) {
+        // ---- the segment: column blocks [blk0, blk0 + n) of one strip of one problem --------------------------------------------------
+        int p = 0;
+        while (p + 1 < count && u0 >= (long)a.p[p + 1].unit0) ++p;
+        p = __builtin_amdgcn_readfirstlane(p);
+        const long ul = u0 - (long)a.p[p].unit0;
+        const int strip = (int)(ul / nblk);
+        const int blk0 = (int)(ul - (long)strip * nblk);
+        const int n = (int)std::min<long>(nblk - blk0, u1 - u0);
+        u0 += n;
+        const int N = pin_s(a.p[p].N), ldx = pin_s(a.p[p].ldx), ldy = pin_s(a.p[p].ldy);
+        const unsigned long long pX = pin_s((unsigned long long)a.p[p].X), pW = pin_s((unsigned long long)a.p[p].img);
+        const unsigned long long pVec = pin_s((unsigned long long)a.p[p].vec), pY = pin_s((unsigned long long)a.p[p].Y);
+        const int row0 = strip * FR, row_w = row0 + wave * 32;
+        const unsigned img_bytes = (unsigned)nblk * (2u * SLOT);
+
+        f32x16 acc[2];
+        u32x4 fr[8][2];
+        float rs[16];
+        unsigned voff[16];
+        float tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        f32x4 cv[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+
+        // ---- W ring prologue: the first three slots of the segment (slot s of the segment = image slot 2 blk0 + s) ---------------------
+        // the image as a raw buffer starting at this wave's 8 KiB of a slot; slots beyond the image read as zeros (bounds check on voff)
+        const u32x4 rsrcW = rebased_rsrc(pW, img_bytes, wslot);
+        unsigned soffW = (unsigned)blk0 * (2u * SLOT);                        // image offset of the slot the next pieces belong to
+        static_for<0, 3>([&](auto SC) {
+            constexpr int s = decltype(SC)::value;
+            static_for<0, PIECES>([&](auto PC) {
+                constexpr int P = decltype(PC)::value;
+                dma_piece(vP[P], rsrcW, std::min(soffW, img_bytes - SLOT), lds0 + s * SLOT + wslot + P * 1024);
+            });
+            soffW += SLOT;
+        });
+
+        // ---- the strip: 32 rows x 512 fp32 -> a[0:255] (raw), row maxima, in-place conversion to the hi / lo fragments ----------------
+        {
+            const int r = std::min(row_w + n31, N - 1);
+            const char* src = (const char*)pX + ((size_t)r * ldx) * 4 + 16 * hh;
+            // quad i: k = 8 i + 4 hh .. + 3 (32 bytes of the row per pair of lanes); two batches (the immediate offset is 13-bit signed)
+            static_for<0, 32>([&](auto IC) { constexpr int i = decltype(IC)::value; agpr_load4<4 * i, 32 * i>(src); });
+            static_for<32, 64>([&](auto IC) { constexpr int i = decltype(IC)::value; agpr_load4<4 * i, 32 * (i - 32)>(src + 1024); });
+            wait_vm<0>();
+            float m0 = 0.f, m1 = 0.f;
+            static_for<0, 128>([&](auto IC) {
+                constexpr int i = decltype(IC)::value;
+                m0 = fmaxf(m0, fabsf(agpr_read<2 * i>()));
+                m1 = fmaxf(m1, fabsf(agpr_read<2 * i + 1>()));
+            });
+            float m = fmaxf(m0, m1);
+            m = fmaxf(m, __shfl_xor(m, 32));
+            const int e = split_exponent(m);
+            const float s = pow2f(9 - e);
+            // sub-step g: hi <- a[8 g .. 8 g + 3], lo <- a[8 g + 4 .. 8 g + 7]; halves e = 0 .. 7 <-> raw registers 8 g + e
+            static_for<0, 32>([&](auto GC) {
+                constexpr int g = decltype(GC)::value;
+                float x[8];
+                static_for<0, 8>([&](auto EC) { constexpr int q = decltype(EC)::value; x[q] = agpr_read<8 * g + q>() * s; });
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const _Float16 h0 = (_Float16)x[2 * q], h1 = (_Float16)x[2 * q + 1];
+                    const _Float16 l0 = (_Float16)(x[2 * q] - (float)h0), l1 = (_Float16)(x[2 * q + 1] - (float)h1);
+                    hi[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    lo[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+                static_for<0, 4>([&](auto QC) {
+                    constexpr int q = decltype(QC)::value;
+                    agpr_write<8 * g + q>(hi[q]);
+                    agpr_write<8 * g + 4 + q>(lo[q]);
+                });
+            });
+            // the epilogue's row scales: lane (n31, hh) needs those of rows 8 q + 4 hh + e -- through LDS (wave-private)
+            float* rsb = (float*)(smem + RS_OFF) + wave * 32;
+            if (hh == 0) rsb[n31] = pow2f(e - 9);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *(const float4*)(rsb + 8 * q + 4 * hh);
+                rs[4 * q] = t.x; rs[4 * q + 1] = t.y; rs[4 * q + 2] = t.z; rs[4 * q + 3] = t.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                voff[i] = ((unsigned)(wave * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)) * (unsigned)ldy + (unsigned)n31) * 4u;
+        }
+        // the output rows of this strip as a raw buffer: rows beyond N are dropped by its bounds check (voff carries the row)
+        const u32x4 rsrcY = rebased_rsrc(pY + (unsigned long long)row0 * (unsigned)ldy * 4ull,
+                                         ((unsigned long long)(std::min(FR, N - row0) - 1) * (unsigned)ldy + (unsigned)(nblk * 32)) * 4ull, 0ull);
+        const u32x4 rsrcNone = {0u, 0u, 0u, 0x00020000u};
+        // the lane constants {cs', b', c1, c0} of column 32 blk + n31: [D][4] floats
+        const u32x4 rsrcV = rebased_rsrc(pVec, (unsigned long long)nblk * 512ull, 0ull);
+        const unsigned cvoff = (unsigned)n31 * 16u;
+
+        // everything the prologue loaded is in registers by now: pin hipcc's own waits here, not inside the hand-counted loops
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(rs[i]), "+v"(voff[i]));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // fragments of sub-steps 0 .. FD - 1 of the first slot
+        static_for<0, FD>([&](auto JC) {
+            constexpr int j = decltype(JC)::value;
+            lds_read128<j * 1024>(fr[j][0], xa0);
+            lds_read128<PLANE + j * 1024>(fr[j][1], xa0);
+        });
+
+        // ---- one micro-op of the epilogue of block `blk - 1` (accumulator set Q, lane constants cv[Q]) --------------------------------
+        u32x4 rsrcYe = rsrcNone;            // the first body's epilogue runs on nothing: an empty buffer drops its stores
+        unsigned soffY = 0u;
+        auto epi_item = [&](auto QC, auto IC, auto DRAIN) {
+            constexpr int Q = decltype(QC)::value;
+            constexpr EpiOp op = STREAM.op[decltype(IC)::value];
+            constexpr int i = op.elem;
+            if constexpr (op.kind == OP_WAITCV) {
+                if constexpr (decltype(DRAIN)::value) wait_vm<0>(); else wait_vm<PLAN.vm_cv>();
+                asm volatile("" : "+v"(cv[Q]));
+            } else if constexpr (op.kind == OP_MUL) {
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(tt[i & 7]) : "v"(acc[Q][i]), "v"(rs[i]));
+            } else if constexpr (op.kind == OP_FMA1) {
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(tt[i & 7]) : "v"(cv[Q].x), "v"(cv[Q].y));
+            } else if constexpr (op.kind == OP_EXP) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(tt[i & 7]));
+            } else if constexpr (op.kind == OP_ADD1) {
+                asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(tt[i & 7]));
+            } else if constexpr (op.kind == OP_RCP) {
+                asm volatile("v_rcp_f32 %0, %0" : "+v"(tt[i & 7]));
+            } else if constexpr (op.kind == OP_MAX) {
+                asm volatile("v_max_f32 %0, 0, %0" : "+v"(tt[i & 7]));
+            } else if constexpr (op.kind == OP_FMA2) {
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(tt[i & 7]) : "v"(cv[Q].z), "v"(cv[Q].w));
+            } else if constexpr (op.kind == OP_ST) {
+                const unsigned vo = voff[i];
+                const u32x4 rsy = rsrcYe;
+                const unsigned so = soffY;
+                const float data = tt[i & 7];
+                asm volatile("buffer_store_dword %0, %1, %2, %3 offen nt" ::"v"(data), "v"(vo), "s"(rsy), "s"(so) : "memory");
+            }
+        };
+
+        // ---- one body: half a column block (ring slot 2 PAR + H), see "the schedule of one column block" --------------------------------
+        auto body = [&](auto PARC, auto HC, int blk) {
+            constexpr int PAR = decltype(PARC)::value, H = decltype(HC)::value, Q = PAR ^ 1;
+            constexpr int RSLOT = 2 * PAR + H;                                   // this body's ring slot
+            constexpr int NSLOT_R = (RSLOT + 1) & 3;                             // the next body's
+            constexpr int DSLOT = (RSLOT + 3) & 3;                               // the slot refilled here: the previous body's
+            const unsigned soff_here = std::min(soffW, img_bytes - SLOT);
+            soffW += SLOT;
+            if constexpr (H == 0) {
+                soffY = (unsigned)(blk - 1) * 128u;
+            }
+            static_for<0, 16>([&](auto JC) {
+                constexpr int J = decltype(JC)::value;
+                constexpr int G = 16 * H + J;                                    // sub-step of the block: strip registers 8 G ..
+                if constexpr (J == BAR_J) {
+                    wait_vm<PLAN.vm_bar[H]>();
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                wait_lgkm<2 * (FD - 1)>();                                       // the two fragments of this sub-step have arrived
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, 3>([&](auto MC) {
+                    constexpr int M = decltype(MC)::value, SG = 48 * H + 3 * J + M;
+                    // lo.hi, hi.lo (small terms first), hi.hi
+                    if constexpr (M == 0) mfma_strip<8 * G + 4, (G == 0)>(acc[PAR], fr[G & 7][0]);
+                    else if constexpr (M == 1) mfma_strip<8 * G, false>(acc[PAR], fr[G & 7][1]);
+                    else mfma_strip<8 * G, false>(acc[PAR], fr[G & 7][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (M == 0) {
+                        // fragments of the sub-step FD ahead (this slot, or the next one behind the barrier)
+                        constexpr int JN = J + FD;
+                        constexpr int RS = JN < 16 ? RSLOT : NSLOT_R, JJ = JN & 15, GN = (G + FD) & 7;
+                        constexpr int OFFS = (RS & 1) * SLOT + JJ * 1024;
+                        if constexpr (RS < 2) {
+                            lds_read128<OFFS>(fr[GN][0], xa0);
+                            lds_read128<OFFS + PLANE>(fr[GN][1], xa0);
+                        } else {
+                            lds_read128<OFFS>(fr[GN][0], xa1);
+                            lds_read128<OFFS + PLANE>(fr[GN][1], xa1);
+                        }
+                    }
+                    if constexpr (slot_cvload(SG)) {
+                        // this block's lane constants (used by its epilogue, in the next block's bodies or in the drain)
+                        const unsigned so = (unsigned)blk * 512u;
+                        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(cv[PAR]) : "v"(cvoff), "s"(rsrcV), "s"(so) : "memory");
+                    }
+                    constexpr int dp = slot_piece(SG);
+                    if constexpr (dp >= 0) dma_piece(vP[dp], rsrcW, soff_here, lds0 + DSLOT * SLOT + wslot + dp * 1024);
+                    static_for<PLAN.begin[SG], PLAN.begin[SG + 1]>([&](auto IC) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        epi_item(std::integral_constant<int, Q>{}, IC, std::false_type{});
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        };
+
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        auto drain = [&](auto QC, int blk) {
+            mfma_drain_nops();
+            rsrcYe = rsrcY;
+            soffY = (unsigned)blk * 128u;
+            static_for<0, STREAM.n>([&](auto IC) { epi_item(QC, IC, std::true_type{}); });
+        };
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[1][e] = 0.0f;
+        {
+            int b = 0;
+#pragma nounroll
+            for (;;) {
+                body(I0{}, I0{}, blk0 + b);
+                body(I0{}, I1{}, blk0 + b);
+                rsrcYe = rsrcY;
+                if (++b >= n) { drain(I0{}, blk0 + b - 1); break; }
+                body(I1{}, I0{}, blk0 + b);
+                body(I1{}, I1{}, blk0 + b);
+                if (++b >= n) { drain(I1{}, blk0 + b - 1); break; }
+            }
+        }
+        // segment end: nothing of this wave may still be in flight towards LDS or the fragment registers
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) asm volatile("" ::"v"(fr[s8][0]), "v"(fr[s8][1]));
+        __builtin_amdgcn_s_barrier();            // every wave is done with the ring before the next segment's prologue refills it
+    }
+    m0_set(m0_keep);
+}
+
+// ---- W [D][512] fp32 (+ bias, BatchNorm, activation) -> the LDS image + the lane-constant table -------------------------------------
+// One workgroup (256 threads) per output column: row maximum -> power-of-two scale (as split_rows_kernel), hi / lo halves scattered
+// into the image {block n / 32}{K half}{plane}{sub-step}{lane = 32 hh + n % 32}{8 halves}.
+__global__ __launch_bounds__(256) void fc_strip_pack_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                            const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, int D,
+                                                            int act, _Float16* __restrict__ img, float* __restrict__ vec) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (n >= D) return;
+    const float x0 = W[(size_t)n * ldw + tid], x1 = W[(size_t)n * ldw + 256 + tid];
+    float m = fmaxf(fabsf(x0), fabsf(x1));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int e = split_exponent(m);
+    const float s = pow2f(9 - e), cs = pow2f(e - 9);
+    const int blk = n >> 5, n31 = n & 31;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int k = t * 256 + tid;
+        const float x = (t ? x1 : x0) * s;
+        const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+        const int j = k >> 4, w = k & 15;
+        const int half = j >> 4, jj = j & 15, hh = (w >> 2) & 1, pos = (w & 3) + 4 * (w >> 3);
+        const size_t base = ((size_t)(blk * 2 + half) * 2) * (PLANE / 2);        // in halves: slot start
+        const size_t at = (size_t)(jj * 64 + 32 * hh + n31) * 8 + pos;
+        img[base + at] = h;
+        img[base + PLANE / 2 + at] = l;
+    }
+    if (tid == 0) {
+        const float b = bias ? bias[n] : 0.f, g = bn_scale ? bn_scale[n] : 1.f, t = bn_shift ? bn_shift[n] : 0.f;
+        float4 c;
+        if (act == LAFF_ACT_TANH) c = make_float4(cs * 2.885390081777927f, b * 2.885390081777927f, -2.f * g, g + t);
+        else if (act == LAFF_ACT_SIGMOID) c = make_float4(cs * -1.4426950408889634f, b * -1.4426950408889634f, g, t);
+        else if (act == LAFF_ACT_RELU) c = make_float4(cs, b, g, t);
+        else c = make_float4(cs * g, fmaf(b, g, t), 0.f, 0.f);
+        *(float4*)(vec + 4 * (size_t)n) = c;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------------
+int g_fc_strip = 1;          // LAFF_FC_STRIP (read when a ctx is created): 0 = never, 1 = default
+
+size_t fc_strip_image_bytes(int D) { return (size_t)(D / 32) * (2 * SLOT) + (size_t)D * 16; }
+size_t fc_strip_vec_offset(int D) { return (size_t)(D / 32) * (2 * SLOT); }
+
+hipError_t launch_fc_strip_pack(const float* W, int ldw, const float* bias, const float* bn_scale, const float* bn_shift, int D, int act,
+                                void* img, hipStream_t st) {
+    hipLaunchKernelGGL(fc_strip_pack_kernel, dim3((unsigned)D), dim3(256), 0, st, W, ldw, bias, bn_scale, bn_shift, D, act,
+                       (_Float16*)img, (float*)((char*)img + fc_strip_vec_offset(D)));
+    return hipGetLastError();
+}
+
+hipError_t launch_fc_strip(FcStripArgs& a, int act, hipStream_t st) {
+    long U = 0;
+    for (int i = 0; i < a.count; ++i) {
+        a.p[i].unit0 = (int)U;
+        U += (long)((a.p[i].N + FR - 1) / FR) * a.nblk;
+    }
+    if (U == 0) return hipSuccess;
+    if (U >= (1l << 31)) return hipErrorInvalidValue;
+    a.total_units = (int)U;
+    const int G = (int)std::min<long>(std::min(g_num_cus, STRIP_MAX_WG), U);
+    a.nranges = G;
+    // Workgroup b runs on XCD b % 8 (observed; only speed depends on it): XCD x takes the contiguous eighth x of the ranges, so its L2
+    // holds the W images of the one or two features its CUs are working on.
+    for (int b = 0; b < G; ++b) a.range_of_wg[b] = (unsigned short)((G % 8 == 0) ? (b % 8) * (G / 8) + b / 8 : b);
+#define LAFF_FCS_LAUNCH(K)                                                                                                    \
+    do {                                                                                                                      \
+        static bool attr = false;                                                                                             \
+        if (!attr) {                                                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)fc_strip_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
+            if (e != hipSuccess) return e;                                                                                    \
+            attr = true;                                                                                                      \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((fc_strip_kernel<K>), dim3((unsigned)G), dim3(256), SMEM, st, a);                                  \
+    } while (0)
+    if (act == LAFF_ACT_TANH || act == LAFF_ACT_SIGMOID) LAFF_FCS_LAUNCH(ACT_EXP);
+    else if (act == LAFF_ACT_RELU) LAFF_FCS_LAUNCH(ACT_RELU);
+    else LAFF_FCS_LAUNCH(ACT_LIN);
+#undef LAFF_FCS_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace laff

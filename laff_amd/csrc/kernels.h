@@ -81,6 +81,32 @@ extern int g_strip_mode, g_strip_map;
 bool sim_strip_eligible(const GemmArgs& a, int mode, bool aligned);
 hipError_t launch_sim_strip(const GemmArgs& a, int mode, hipStream_t st);
 
+// ---- strip form of the FC projection at K = 512 (fc_strip.hip): X stationary in registers, W streamed from a packed LDS image ----
+constexpr int FC_STRIP_ROWS = 128;       // input rows per strip (4 wavefronts x 32 rows held in registers)
+constexpr int FC_STRIP_K = 512;
+struct FcStripProblem {
+    const float* X;           // [N][ldx] fp32, 16-byte aligned rows
+    const void* img;          // laff_fc_strip_pack: D / 32 blocks x 2 K-halves x 32 KiB {hi, lo} + [D][4] lane constants
+    const float* vec;         // the lane constants inside img
+    float* Y;                 // [N][ldy]
+    int ldx, ldy, N;
+    int unit0;                // first (strip, column block) unit of this problem in the launch (filled by launch_fc_strip)
+};
+struct FcStripArgs {
+    int count;
+    int nblk;                 // D / 32, the same for every problem of a launch
+    int nranges;              // == gridDim.x
+    int total_units;
+    FcStripProblem p[MAX_GROUP];
+    unsigned short range_of_wg[STRIP_MAX_WG];
+};
+extern int g_fc_strip;
+size_t fc_strip_image_bytes(int D);
+size_t fc_strip_vec_offset(int D);
+hipError_t launch_fc_strip_pack(const float* W, int ldw, const float* bias, const float* bn_scale, const float* bn_shift, int D, int act,
+                                void* img, hipStream_t st);
+hipError_t launch_fc_strip(FcStripArgs& a, int act, hipStream_t st);
+
 hipError_t launch_gemm_nt(const GemmArgs& a, int mode, bool aligned, hipStream_t st);
 hipError_t launch_gemm_nt_grouped_f32(GroupedGemmArgs& g, int staging, hipStream_t st);
 hipError_t launch_gemm_nt_grouped_f16(GroupedGemmArgs& g, hipStream_t st);

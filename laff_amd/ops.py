@@ -10,9 +10,9 @@ import torch
 
 from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
-                   FcProblem, FcSplitProblem, Plane, check, FcFusedProblem, RankSide)
+                   FcProblem, FcSplitProblem, FcStripProblem, Plane, check, FcFusedProblem, RankSide)
 
-__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'topk_from_operands', 'alloc_scores', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts', 'FusedPrepare', 'fused_prepare_eligible',
+__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'topk_from_operands', 'alloc_scores', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'fc_strip_pack', 'fc_strip_eligible', 'fc_act_bn_strip_grouped', 'StripWeights', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts', 'FusedPrepare', 'fused_prepare_eligible',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -326,6 +326,65 @@ def fc_act_bn_fused_grouped(problems):
         keep.append((x, ws, vecs))
     _call('row_scales', lib.laff_row_scales_grouped, h, n, X, N, K, LD, R)
     _call('fc_act_bn', lib.laff_fc_act_bn_fused_grouped, h, arr, n)
+    return outs
+
+
+class StripWeights:
+    """A TransformNet's parameters packed for the strip-form FC (laff_fc_strip_pack): the W stream's LDS image + the per-column
+    epilogue constants (bias, activation and folded BatchNorm combined)."""
+
+    def __init__(self, img, D, K, act):
+        self.img, self.D, self.K, self.act = img, D, K, act
+
+
+def fc_strip_pack(weight, bias=None, bn_scale=None, bn_shift=None, activation=None):
+    """Pack W [D, 512] (+ bias / folded BatchNorm / activation) once per model for fc_act_bn_strip_grouped."""
+    w, ldw = _rows(weight, 'weight')
+    D, K = w.shape
+    lib, h = _context(w.device)
+    nbytes = C.c_size_t()
+    check(lib.laff_fc_strip_pack_bytes(D, K, C.byref(nbytes)))
+    for t, nm in ((bias, 'bias'), (bn_scale, 'bn_scale'), (bn_shift, 'bn_shift')):
+        if t is not None:
+            _dev(t, nm)
+            if t.numel() != D or not t.is_contiguous():
+                raise ValueError('%s must be a contiguous vector of %d' % (nm, D))
+    img = torch.empty((nbytes.value,), device=w.device, dtype=torch.uint8)
+    _call('fc_strip_pack', lib.laff_fc_strip_pack, h, _ptr(w), ldw, _ptr(bias), _ptr(bn_scale), _ptr(bn_shift), D, K, ACT[activation],
+          _ptr(img))
+    return StripWeights(img, D, K, ACT[activation])
+
+
+def fc_strip_eligible(x, D):
+    """Can laff_fc_act_bn_strip_grouped take this input?  (fp32 CUDA matrix of 512 columns, 16-byte aligned rows, D % 32 == 0.)"""
+    return (torch.is_tensor(x) and x.is_cuda and x.layout == torch.strided and x.dtype == torch.float32 and x.dim() == 2 and
+            x.shape[1] == 512 and x.stride(1) == 1 and (x.stride(0) % 4 == 0 or x.shape[0] <= 1) and x.data_ptr() % 16 == 0 and
+            D % 32 == 0 and D >= 32)
+
+
+def fc_act_bn_strip_grouped(problems):
+    """TransformNet.forward for several features in the strip form (X stationary in registers, no row-scale pass).
+    problems: dicts with x (fp32 tensor [N, 512]), strip (StripWeights), optional out.  Returns the list of outputs."""
+    if not problems:
+        return []
+    n = len(problems)
+    arr = (FcStripProblem * n)()
+    outs, keep = [], []
+    dev = problems[0]['strip'].img.device
+    for i, q in enumerate(problems):
+        x, ldx = _rows(q['x'], 'x')
+        sw = q['strip']
+        if not fc_strip_eligible(x, sw.D):
+            raise ValueError('problem %d is not eligible for the strip form (see fc_strip_eligible)' % i)
+        out = q.get('out')
+        if out is None:
+            out = torch.empty((x.shape[0], sw.D), device=dev, dtype=torch.float32)
+        y, ldy = _rows(out, 'out')
+        arr[i] = FcStripProblem(x.data_ptr(), max(ldx, 512), x.shape[0], sw.img.data_ptr(), sw.D, sw.act, y.data_ptr(), ldy)
+        outs.append(out)
+        keep.append((x, sw))
+    lib, h = _context(dev)
+    _call('fc_act_bn', lib.laff_fc_act_bn_strip_grouped, h, arr, n)
     return outs
 
 
