@@ -225,6 +225,15 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
     const unsigned xa0 = lds0 + lane16, xa1 = lds0 + lane16 + 2u * SLOT;      // fragment addresses: ring slots 0, 1 | 2, 3
     const unsigned wslot = (unsigned)wave * (PIECES * 1024u);                   // this wave's 8 KiB of a slot (LDS and source offset)
     const unsigned m0_keep = m0_get();
+#ifdef LAFF_FCS_TRACE
+    // debug build: cycle stamps of wave 0 -- per segment s (up to 8): base 8 s: +0 start, +1 ring prologue + strip loads issued, +2 strip
+    // landed, +3 row maxima, +4 converted, +5 barrier passed, +6 block loop done, +7 drained | [64 + s] = blocks of the segment
+    unsigned long long* const trc = a.trace ? a.trace + (size_t)blockIdx.x * 80 : nullptr;
+    int trc_seg = 0;
+#define STAMP(i) do { if (trc && tid == 0 && trc_seg < 8) trc[8 * trc_seg + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
     while (u0 < u1) {
         // ---- the segment: column blocks [blk0, blk0 + n) of one strip of one problem --------------------------------------------------
@@ -236,6 +245,10 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         const int blk0 = (int)(ul - (long)strip * nblk);
         const int n = (int)std::min<long>(nblk - blk0, u1 - u0);
         u0 += n;
+        STAMP(0);
+#ifdef LAFF_FCS_TRACE
+        if (trc && tid == 0 && trc_seg < 8) trc[64 + trc_seg] = (unsigned long long)n;
+#endif
         const int N = pin_s(a.p[p].N), ldx = pin_s(a.p[p].ldx), ldy = pin_s(a.p[p].ldy);
         const unsigned long long pX = pin_s((unsigned long long)a.p[p].X), pW = pin_s((unsigned long long)a.p[p].img);
         const unsigned long long pVec = pin_s((unsigned long long)a.p[p].vec), pY = pin_s((unsigned long long)a.p[p].Y);
@@ -269,7 +282,9 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             // quad i: k = 8 i + 4 hh .. + 3 (32 bytes of the row per pair of lanes); two batches (the immediate offset is 13-bit signed)
             static_for<0, 32>([&](auto IC) { constexpr int i = decltype(IC)::value; agpr_load4<4 * i, 32 * i>(src); });
             static_for<32, 64>([&](auto IC) { constexpr int i = decltype(IC)::value; agpr_load4<4 * i, 32 * (i - 32)>(src + 1024); });
+            STAMP(1);
             wait_vm<0>();
+            STAMP(2);
             float m0 = 0.f, m1 = 0.f;
             static_for<0, 128>([&](auto IC) {
                 constexpr int i = decltype(IC)::value;
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             m = fmaxf(m, __shfl_xor(m, 32));
             const int e = split_exponent(m);
             const float s = pow2f(9 - e);
+            STAMP(3);
             // sub-step g: hi <- a[8 g .. 8 g + 3], lo <- a[8 g + 4 .. 8 g + 7]; halves e = 0 .. 7 <-> raw registers 8 g + e
             static_for<0, 32>([&](auto GC) {
                 constexpr int g = decltype(GC)::value;
@@ -299,6 +315,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                     agpr_write<8 * g + 4 + q>(lo[q]);
                 });
             });
+            STAMP(4);
             // the epilogue's row scales: lane (n31, hh) needs those of rows 8 q + 4 hh + e -- through LDS (wave-private)
             float* rsb = (float*)(smem + RS_OFF) + wave * 32;
             if (hh == 0) rsb[n31] = pow2f(e - 9);
@@ -326,6 +343,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(rs[i]), "+v"(voff[i]));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        STAMP(5);
         // fragments of sub-steps 0 .. FD - 1 of the first slot
         static_for<0, FD>([&](auto JC) {
             constexpr int j = decltype(JC)::value;
@@ -426,6 +444,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         auto drain = [&](auto QC, int blk) {
+            STAMP(6);
             mfma_drain_nops();
             rsrcYe = rsrcY;
             soffY = (unsigned)blk * 128u;
@@ -451,8 +470,13 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) asm volatile("" ::"v"(fr[s8][0]), "v"(fr[s8][1]));
         __builtin_amdgcn_s_barrier();            // every wave is done with the ring before the next segment's prologue refills it
+        STAMP(7);
+#ifdef LAFF_FCS_TRACE
+        ++trc_seg;
+#endif
     }
     m0_set(m0_keep);
+#undef STAMP
 }
 
 // ---- W [D][512] fp32 (+ bias, BatchNorm, activation) -> the LDS image + the lane-constant table -------------------------------------
@@ -519,6 +543,8 @@ hipError_t launch_fc_strip(FcStripArgs& a, int act, hipStream_t st) {
     if (U == 0) return hipSuccess;
     if (U >= (1l << 31)) return hipErrorInvalidValue;
     a.total_units = (int)U;
+    a.trace = nullptr;
+    if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);   // debug builds only
     const int G = (int)std::min<long>(std::min(g_num_cus, STRIP_MAX_WG), U);
     a.nranges = G;
     // Workgroup b runs on XCD b % 8 (observed; only speed depends on it): XCD x takes the contiguous eighth x of the ranges, so its L2

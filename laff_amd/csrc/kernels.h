@@ -97,6 +97,7 @@ struct FcStripArgs {
     int nblk;                 // D / 32, the same for every problem of a launch
     int nranges;              // == gridDim.x
     int total_units;
+    unsigned long long* trace;   // debug (LAFF_FCS_TRACE build only): 80 words per workgroup
     FcStripProblem p[MAX_GROUP];
     unsigned short range_of_wg[STRIP_MAX_WG];
 };

@@ -36,6 +36,9 @@ FC_PRECISION = 'fp32'
 GATHER_IN_FUSE = os.environ.get('LAFF_GATHER_IN_FUSE', '1') != '0'
 #: fp16x3 only: split the inputs inside the GEMM instead of materialising their hi/lo planes (LAFF_FUSED_SPLIT=0 disables)
 FUSED_SPLIT = os.environ.get('LAFF_FUSED_SPLIT', '1') != '0'
+#: fp16x3 only: projections of 512-d inputs take the strip form (X stationary in registers: no row-scale pass, no split planes;
+#: laff_fc_act_bn_strip_grouped).  LAFF_FC_STRIP=0 keeps the tiled kernels.
+FC_STRIP = os.environ.get('LAFF_FC_STRIP', '1') != '0'
 
 
 def _row_chunks(pending, limit_bytes=1 << 31):
@@ -108,6 +111,18 @@ def run_fc(pending):
 
 
 def _run_fc_x3(pending):
+    if FC_STRIP:
+        strip = [q for q in pending if q.get('strip') is not None and ops.fc_strip_eligible(q['x'], q['weight'].shape[0])]
+        if strip:
+            rest = [q for q in pending if not any(q is s for s in strip)]
+            outs = {id(q): o for q, o in zip(strip, ops.fc_act_bn_strip_grouped([dict(q, strip=q['strip']()) for q in strip]))}
+            if rest:
+                outs.update({id(q): o for q, o in zip(rest, _run_fc_x3_tiled(rest))})
+            return [outs[id(q)] for q in pending]
+    return _run_fc_x3_tiled(pending)
+
+
+def _run_fc_x3_tiled(pending):
     # big launches with a narrow output take the fused split (inputs stay fp32 in HBM, split inside the GEMM: every column
     # tile of a row block repeats the conversion, 2x at D = 512 but 16x at D = 4096, where materialising the planes once is
     # cheaper: C5 33.2 ms fused vs 32.9 ms); small launches take the materialised split, whose 128x128 tiles fill the chip
@@ -231,6 +246,16 @@ class TransformNet(nn.Module):
             self._w_split = (key, ops.split_rows(w.detach()))
         return self._w_split[1]
 
+    def strip_weights(self):
+        """fc1 + folded BatchNorm + activation packed for the strip-form FC (laff_fc_strip_pack), cached until a parameter changes."""
+        scale, shift = self.bn_affine(None)
+        w, b = self.fc1.weight, self.fc1.bias
+        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version),
+               None if self.bn1 is None else self._bn_cache[0], self.activation_name)
+        if getattr(self, '_w_strip', None) is None or self._w_strip[0] != key:
+            self._w_strip = (key, ops.fc_strip_pack(w.detach(), None if b is None else b.detach(), scale, shift, self.activation_name))
+        return self._w_strip[1]
+
     def plane(self, x, heads=1, extra_shift=None, pending=None, head_dim=None):
         """(src, tile, scale, shift) for laff_fuse.  With an FC the projection either runs now or, when `pending`
         (a list) is given, is appended to it so that the caller launches all features' GEMMs as one grouped kernel."""
@@ -249,6 +274,9 @@ class TransformNet(nn.Module):
             prob = dict(x=x, weight=self.fc1.weight.detach(), weight_split=self.weight_split(),
                         bias=self.fc1.bias.detach() if self.fc1.bias is not None else None,
                         bn_scale=scale, bn_shift=shift, activation=self.activation_name)
+            if (FC_PRECISION == 'fp16x3' and FC_STRIP and extra_shift is None and not DEFER_ACTIVATION and
+                    self.fc1.in_features == 512 and self.out_features % 32 == 0):
+                prob['strip'] = self.strip_weights        # packed lazily: only if the launch takes the strip form
             if pending is None or not DEFER_ACTIVATION:
                 if pending is None:
                     return (run_fc([prob])[0], False, None, None)

@@ -64,7 +64,7 @@ def _dev(t, name, dtype=torch.float32):
 def _rows(t, name):
     """2-D view with unit inner stride; returns (tensor, ld)."""
     _dev(t, name)
-    if t.dim() != 2 or t.stride(1) != 1:
+    if t.dim() != 2 or (t.numel() and t.stride(1) != 1):
         raise ValueError('%s must be 2-D with contiguous rows, got shape %s strides %s' % (name, tuple(t.shape), t.stride()))
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
 
@@ -358,8 +358,8 @@ def fc_strip_pack(weight, bias=None, bn_scale=None, bn_shift=None, activation=No
 def fc_strip_eligible(x, D):
     """Can laff_fc_act_bn_strip_grouped take this input?  (fp32 CUDA matrix of 512 columns, 16-byte aligned rows, D % 32 == 0.)"""
     return (torch.is_tensor(x) and x.is_cuda and x.layout == torch.strided and x.dtype == torch.float32 and x.dim() == 2 and
-            x.shape[1] == 512 and x.stride(1) == 1 and (x.stride(0) % 4 == 0 or x.shape[0] <= 1) and x.data_ptr() % 16 == 0 and
-            D % 32 == 0 and D >= 32)
+            x.shape[1] == 512 and (x.shape[0] == 0 or (x.stride(1) == 1 and (x.stride(0) % 4 == 0 or x.shape[0] == 1) and
+                                                       x.data_ptr() % 16 == 0)) and D % 32 == 0 and D >= 32)
 
 
 def fc_act_bn_strip_grouped(problems):
