@@ -54,7 +54,9 @@ constexpr int RS_OFF = RING * SLOT;            // per wave: 32 row scales (fp32)
 constexpr int SMEM = RS_OFF + 4 * 128;
 static_assert(SMEM <= 160 * 1024, "LDS budget");
 
-constexpr int FD = 6;                          // fragment reads run FD sub-steps ahead, 8 register sets
+constexpr int FD = 6;                          // fragment reads run FD sub-steps ahead,
+constexpr int NSETS = 8;                       // into 8 register sets (two planes each; 32 sub-steps per block: a divisor of 32)
+static_assert(32 % NSETS == 0 && FD < NSETS, "the set of a sub-step must not depend on the block");
 constexpr int BAR_J = 16 - FD;                 // the body's barrier sits in front of this sub-step
 constexpr int NSLOT = 96;                      // MFMA issue slots of a column block: 2 bodies x 16 sub-steps x 3
 
@@ -92,8 +94,31 @@ __device__ __forceinline__ void lds_read128(u32x4& d, unsigned addr) {
 }
 
 // one 1 KiB piece of the W stream, straight into LDS (lane L lands at M0 base + 16 L; the image is already in LDS order)
-__device__ __forceinline__ void dma_piece(unsigned voff, u32x4 rsrc, unsigned soff, unsigned m0val) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(m0val) : "memory");
+template <int LDSOFF>
+__device__ __forceinline__ void dma_piece(unsigned voff, u32x4 rsrc, unsigned soff, unsigned m0base) {
+    asm volatile("s_add_i32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 ::"v"(voff), "s"(rsrc), "s"(soff), "s"(m0base), "n"(LDSOFF) : "memory", "scc");
+}
+
+// 1 KiB of input rows straight into LDS (lane L lands at M0 base + LDSOFF + 16 L): scalar base + per-lane 32-bit offset.  (No
+// immediate offset: the instruction's offset field moves the LDS address as well as the global one.)
+template <int LDSOFF>
+__device__ __forceinline__ void dma_rows(unsigned voff, unsigned long long base, unsigned m0base) {
+    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 ::"v"(voff), "s"(base), "s"(m0base), "n"(LDSOFF) : "memory", "scc");
+}
+// 16 bytes of the LDS staging -> a[R .. R + 3]
+template <int R, int IMM>
+__device__ __forceinline__ void lds_to_agpr(unsigned addr) {
+    asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "n"(R), "n"(R + 3), "n"(IMM) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ void pin_v(T& x) { asm volatile("" : "+v"(x)); }
+// address = voff0 + ROWMUL * ldy4, made right in front of the store (one address register instead of one per accumulator)
+template <int ROWMUL>
+__device__ __forceinline__ void store_row(unsigned& tmp, float data, unsigned voff0, unsigned ldy4, u32x4 rsrc, unsigned soff) {
+    asm volatile("v_mad_u32_u24 %0, %3, %4, %2\n\tbuffer_store_dword %1, %0, %5, %6 offen nt"
+                 : "=&v"(tmp) : "v"(data), "v"(voff0), "s"(ldy4), "n"(ROWMUL), "s"(rsrc), "s"(soff) : "memory");
 }
 
 // row maximum -> exponent of the power-of-two scale: same rule as split_rows_kernel (fuse.hip): maximum scaled into [512, 1024)
@@ -103,6 +128,16 @@ __device__ __forceinline__ int split_exponent(float m) {
     return max(be - 127, -100);
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+__device__ __forceinline__ void absmax3(float& m, float x, float y) { asm volatile("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(x), "v"(y)); }
+// hi = f16(x s) for two values (x s is exact: s is a power of two), the residuals x s - hi (exact in fp32) replace x, lo = f16(residual):
+// the arithmetic of split_rows_kernel (fuse.hip)
+__device__ __forceinline__ void split_pair(float& x0, float& x1, float s, unsigned& hi, unsigned& lo) {
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "v"(s));
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "v"(s));
+    asm volatile("v_fma_mix_f32 %0, %0, %1, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "+v"(x0) : "v"(s), "v"(hi));
+    asm volatile("v_fma_mix_f32 %0, %0, %1, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(x1) : "v"(s), "v"(hi));
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(x0), "v"(x1));
+}
 
 // ---- the epilogue of a column block as a static stream of micro-ops -----------------------------------------------------------------
 // Per accumulator i (row 8 (i >> 2) + 4 hh + (i & 3) of the wave's 32, the lane's column):
@@ -117,7 +152,7 @@ enum : unsigned char { OP_WAITCV = 0, OP_MUL, OP_FMA1, OP_EXP, OP_ADD1, OP_RCP, 
 enum { ACT_LIN = 0, ACT_RELU = 1, ACT_EXP = 2 };                 // epilogue kinds (template parameter)
 struct EpiOp { unsigned char kind, elem; };
 struct EpiStream { EpiOp op[160]; int n; };
-constexpr int op_cost(unsigned char k) { return (k == OP_EXP || k == OP_RCP) ? 3 : (k == OP_WAITCV ? 0 : 1); }
+constexpr int op_cost(unsigned char k) { return (k == OP_EXP || k == OP_RCP) ? 3 : (k == OP_WAITCV ? 0 : (k == OP_ST ? 2 : 1)); }
 
 template <int ACTK>
 constexpr EpiStream make_stream() {
@@ -209,8 +244,9 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
     const int nranges = pin_s(a.nranges);
     const long U = (long)pin_s((unsigned)a.total_units);
     const int myrange = a.range_of_wg[blockIdx.x];
-    long u0 = U * myrange / nranges;
-    const long u1 = U * (myrange + 1) / nranges;
+    int u0 = pin_s((int)(U * myrange / nranges));              // (U < 2^31: launch_fc_strip)
+    const int u1 = pin_s((int)(U * (myrange + 1) / nranges));
+    const unsigned img_bytes = (unsigned)nblk * (2u * SLOT);
 
     constexpr Plan PLAN = make_plan<ACTK>();
     constexpr EpiStream STREAM = make_stream<ACTK>();
@@ -224,10 +260,14 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
     for (int P = 0; P < PIECES; ++P) { vP[P] = lane16 + 1024u * P; asm volatile("" : "+v"(vP[P])); }
     const unsigned xa0 = lds0 + lane16, xa1 = lds0 + lane16 + 2u * SLOT;      // fragment addresses: ring slots 0, 1 | 2, 3
     const unsigned wslot = (unsigned)wave * (PIECES * 1024u);                   // this wave's 8 KiB of a slot (LDS and source offset)
+    const unsigned ldsw = pin_s(lds0 + wslot);                                  // LDS address of this wave's 8 KiB of ring slot 0
+    const unsigned stg = pin_s(lds0 + (unsigned)wave * (unsigned)SLOT);         // strip staging: this wave's QUARTER of the (idle) ring
+    const unsigned cvoff = (unsigned)n31 * 16u;
+    float* const rsb = (float*)(smem + RS_OFF) + wave * 32;                     // this wave's 32 row scales (wave-private exchange)
     const unsigned m0_keep = m0_get();
 #ifdef LAFF_FCS_TRACE
-    // debug build: cycle stamps of wave 0 -- per segment s (up to 8): base 8 s: +0 start, +1 ring prologue + strip loads issued, +2 strip
-    // landed, +3 row maxima, +4 converted, +5 barrier passed, +6 block loop done, +7 drained | [64 + s] = blocks of the segment
+    // debug build: cycle stamps of wave 0 -- per segment s (up to 8): base 8 s: +0 start, +1 strip in the registers (raw), +2 row maxima,
+    // +3 converted, +4 ring prologue landed + barrier, +5 block loop done, +6 drained + segment end | [64 + s] = blocks of the segment
     unsigned long long* const trc = a.trace ? a.trace + (size_t)blockIdx.x * 80 : nullptr;
     int trc_seg = 0;
 #define STAMP(i) do { if (trc && tid == 0 && trc_seg < 8) trc[8 * trc_seg + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -238,12 +278,12 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
     while (u0 < u1) {
         // ---- the segment: column blocks [blk0, blk0 + n) of one strip of one problem --------------------------------------------------
         int p = 0;
-        while (p + 1 < count && u0 >= (long)a.p[p + 1].unit0) ++p;
+        while (p + 1 < count && u0 >= a.p[p + 1].unit0) ++p;
         p = __builtin_amdgcn_readfirstlane(p);
-        const long ul = u0 - (long)a.p[p].unit0;
-        const int strip = (int)(ul / nblk);
-        const int blk0 = (int)(ul - (long)strip * nblk);
-        const int n = (int)std::min<long>(nblk - blk0, u1 - u0);
+        const int ul = u0 - a.p[p].unit0;
+        const int strip = __builtin_amdgcn_readfirstlane(ul / nblk);
+        const int blk0 = __builtin_amdgcn_readfirstlane(ul - strip * nblk);
+        const int n = __builtin_amdgcn_readfirstlane(std::min(nblk - blk0, u1 - u0));
         u0 += n;
         STAMP(0);
 #ifdef LAFF_FCS_TRACE
@@ -253,97 +293,144 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         const unsigned long long pX = pin_s((unsigned long long)a.p[p].X), pW = pin_s((unsigned long long)a.p[p].img);
         const unsigned long long pVec = pin_s((unsigned long long)a.p[p].vec), pY = pin_s((unsigned long long)a.p[p].Y);
         const int row0 = strip * FR, row_w = row0 + wave * 32;
-        const unsigned img_bytes = (unsigned)nblk * (2u * SLOT);
 
         f32x16 acc[2];
-        u32x4 fr[8][2];
+        u32x4 fr[NSETS][2];
         float rs[16];
-        unsigned voff[16];
         float tt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned ta[4] = {0, 0, 0, 0};
         f32x4 cv[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 
-        // ---- W ring prologue: the first three slots of the segment (slot s of the segment = image slot 2 blk0 + s) ---------------------
-        // the image as a raw buffer starting at this wave's 8 KiB of a slot; slots beyond the image read as zeros (bounds check on voff)
+        // ---- the strip: this wave's 32 rows x 512 fp32 -> a[0:255].  The rows come in by LDS-DMA, 2 rows x 512 contiguous bytes per
+        // instruction (direct 16-byte loads in the fragment layout touch 32 rows per instruction and run at a fifth of the rate), in four
+        // rounds of one K quarter each (16 KiB) through two buffers in this wave's quarter of the idle ring; the source piece is
+        // swizzled (piece ^ (row & 15)) so that the fragment-order read-back -- lane (row n31, half hh) takes 16-byte pieces 4 cc + hh and
+        // 4 cc + 2 + hh of chunk cc -- is conflict-free, and that read-back goes straight into the accumulator registers. ----
+        {
+            const unsigned long long xbase = pX + (unsigned long long)row0 * (unsigned)ldx * 4ull;
+            // instruction t of a round: rows 2 t + (lane >> 5), LDS position (lane & 31) <- source piece (lane & 31) ^ (row & 15)
+            unsigned sv[16];
+            const unsigned base_x = ((unsigned)lane & 31u) ^ (unsigned)hh;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int r = std::min(row_w + 2 * t + hh, N - 1) - row0;
+                sv[t] = (unsigned)r * (unsigned)ldx * 4u + ((base_x ^ (unsigned)((2 * t) & 15)) << 4);
+            }
+            // read-back addresses: piece = 4 cc + 2 quad + hh (cc = chunk within the quarter): the low four bits take the swizzle
+            unsigned XA[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                XA[j] = stg + (unsigned)n31 * 512u + ((((unsigned)(4 * (j >> 1) + 2 * (j & 1) + hh)) ^ ((unsigned)n31 & 15u)) << 4);
+            auto issue_round = [&](auto QC) {
+                constexpr int q = decltype(QC)::value;
+                const unsigned long long qbase = xbase + (unsigned long long)(q * 512);
+                static_for<0, 16>([&](auto TC) {
+                    constexpr int t = decltype(TC)::value;
+                    dma_rows<(q & 1) * 16384 + t * 1024>(sv[t], qbase, stg);
+                });
+            };
+            auto read_round = [&](auto QC) {
+                constexpr int q = decltype(QC)::value;
+                static_for<0, 8>([&](auto CC) {
+                    constexpr int cc = decltype(CC)::value, c = 8 * q + cc;
+                    constexpr int IMM = (q & 1) * 16384 + 256 * (cc >> 2);
+                    lds_to_agpr<8 * c, IMM>(XA[2 * (cc & 3)]);
+                    lds_to_agpr<8 * c + 4, IMM>(XA[2 * (cc & 3) + 1]);
+                });
+            };
+            using Q0 = std::integral_constant<int, 0>;
+            using Q1 = std::integral_constant<int, 1>;
+            using Q2 = std::integral_constant<int, 2>;
+            using Q3 = std::integral_constant<int, 3>;
+            issue_round(Q0{});
+            issue_round(Q1{});
+            wait_vm<16>();
+            read_round(Q0{});
+            wait_lgkm<0>();
+            issue_round(Q2{});
+            wait_vm<16>();
+            read_round(Q1{});
+            wait_lgkm<0>();
+            issue_round(Q3{});
+            wait_vm<16>();
+            read_round(Q2{});
+            wait_vm<0>();
+            read_round(Q3{});
+            wait_lgkm<0>();
+        }
+        __builtin_amdgcn_s_barrier();            // every wave has emptied its staging quarter: the ring may fill
+        asm volatile("" ::: "memory");
+        STAMP(1);
+
+        // ---- W ring prologue: the first three slots of the segment (slot s of the segment = image slot 2 blk0 + s); it lands while the
+        // strip is converted.  The image as a raw buffer starting at this wave's 8 KiB of a slot ----
         const u32x4 rsrcW = rebased_rsrc(pW, img_bytes, wslot);
         unsigned soffW = (unsigned)blk0 * (2u * SLOT);                        // image offset of the slot the next pieces belong to
         static_for<0, 3>([&](auto SC) {
             constexpr int s = decltype(SC)::value;
             static_for<0, PIECES>([&](auto PC) {
                 constexpr int P = decltype(PC)::value;
-                dma_piece(vP[P], rsrcW, std::min(soffW, img_bytes - SLOT), lds0 + s * SLOT + wslot + P * 1024);
+                dma_piece<s * SLOT + P * 1024>(vP[P], rsrcW, std::min(soffW, img_bytes - SLOT), ldsw);
             });
             soffW += SLOT;
         });
 
-        // ---- the strip: 32 rows x 512 fp32 -> a[0:255] (raw), row maxima, in-place conversion to the hi / lo fragments ----------------
+        // ---- row maxima (a row lives in lanes l and l + 32), scale, in-place conversion to the hi / lo fragments ----
         {
-            const int r = std::min(row_w + n31, N - 1);
-            const char* src = (const char*)pX + ((size_t)r * ldx) * 4 + 16 * hh;
-            // quad i: k = 8 i + 4 hh .. + 3 (32 bytes of the row per pair of lanes); two batches (the immediate offset is 13-bit signed)
-            static_for<0, 32>([&](auto IC) { constexpr int i = decltype(IC)::value; agpr_load4<4 * i, 32 * i>(src); });
-            static_for<32, 64>([&](auto IC) { constexpr int i = decltype(IC)::value; agpr_load4<4 * i, 32 * (i - 32)>(src + 1024); });
-            STAMP(1);
-            wait_vm<0>();
-            STAMP(2);
             float m0 = 0.f, m1 = 0.f;
-            static_for<0, 128>([&](auto IC) {
+            static_for<0, 64>([&](auto IC) {
                 constexpr int i = decltype(IC)::value;
-                m0 = fmaxf(m0, fabsf(agpr_read<2 * i>()));
-                m1 = fmaxf(m1, fabsf(agpr_read<2 * i + 1>()));
+                const float x0 = agpr_read<4 * i>(), x1 = agpr_read<4 * i + 1>(), x2 = agpr_read<4 * i + 2>(), x3 = agpr_read<4 * i + 3>();
+                absmax3(m0, x0, x1);
+                absmax3(m1, x2, x3);
             });
             float m = fmaxf(m0, m1);
             m = fmaxf(m, __shfl_xor(m, 32));
             const int e = split_exponent(m);
             const float s = pow2f(9 - e);
-            STAMP(3);
+            STAMP(2);
             // sub-step g: hi <- a[8 g .. 8 g + 3], lo <- a[8 g + 4 .. 8 g + 7]; halves e = 0 .. 7 <-> raw registers 8 g + e
             static_for<0, 32>([&](auto GC) {
                 constexpr int g = decltype(GC)::value;
                 float x[8];
-                static_for<0, 8>([&](auto EC) { constexpr int q = decltype(EC)::value; x[q] = agpr_read<8 * g + q>() * s; });
+                static_for<0, 8>([&](auto EC) { constexpr int q = decltype(EC)::value; x[q] = agpr_read<8 * g + q>(); });
                 unsigned hi[4], lo[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const _Float16 h0 = (_Float16)x[2 * q], h1 = (_Float16)x[2 * q + 1];
-                    const _Float16 l0 = (_Float16)(x[2 * q] - (float)h0), l1 = (_Float16)(x[2 * q + 1] - (float)h1);
-                    hi[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                    lo[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-                }
+                for (int q = 0; q < 4; ++q) split_pair(x[2 * q], x[2 * q + 1], s, hi[q], lo[q]);
                 static_for<0, 4>([&](auto QC) {
                     constexpr int q = decltype(QC)::value;
                     agpr_write<8 * g + q>(hi[q]);
                     agpr_write<8 * g + 4 + q>(lo[q]);
                 });
             });
-            STAMP(4);
+            STAMP(3);
             // the epilogue's row scales: lane (n31, hh) needs those of rows 8 q + 4 hh + e -- through LDS (wave-private)
-            float* rsb = (float*)(smem + RS_OFF) + wave * 32;
             if (hh == 0) rsb[n31] = pow2f(e - 9);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 t = *(const float4*)(rsb + 8 * q + 4 * hh);
                 rs[4 * q] = t.x; rs[4 * q + 1] = t.y; rs[4 * q + 2] = t.z; rs[4 * q + 3] = t.w;
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                voff[i] = ((unsigned)(wave * 32 + 8 * (i >> 2) + 4 * hh + (i & 3)) * (unsigned)ldy + (unsigned)n31) * 4u;
         }
+        // output addressing: row 8 q + 4 hh + e of the wave's 32 at voff0 + (8 q + e) ldy4
+        const unsigned ldy4 = (unsigned)ldy * 4u;
+        unsigned voff0 = ((unsigned)(wave * 32 + 4 * hh) * (unsigned)ldy + (unsigned)n31) * 4u;
         // the output rows of this strip as a raw buffer: rows beyond N are dropped by its bounds check (voff carries the row)
         const u32x4 rsrcY = rebased_rsrc(pY + (unsigned long long)row0 * (unsigned)ldy * 4ull,
                                          ((unsigned long long)(std::min(FR, N - row0) - 1) * (unsigned)ldy + (unsigned)(nblk * 32)) * 4ull, 0ull);
         const u32x4 rsrcNone = {0u, 0u, 0u, 0x00020000u};
         // the lane constants {cs', b', c1, c0} of column 32 blk + n31: [D][4] floats
         const u32x4 rsrcV = rebased_rsrc(pVec, (unsigned long long)nblk * 512ull, 0ull);
-        const unsigned cvoff = (unsigned)n31 * 16u;
 
         // everything the prologue loaded is in registers by now: pin hipcc's own waits here, not inside the hand-counted loops
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(rs[i]), "+v"(voff[i]));
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(rs[i]));
+        asm volatile("" : "+v"(voff0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        STAMP(5);
+        STAMP(4);
         // fragments of sub-steps 0 .. FD - 1 of the first slot
         static_for<0, FD>([&](auto JC) {
             constexpr int j = decltype(JC)::value;
@@ -376,11 +463,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             } else if constexpr (op.kind == OP_FMA2) {
                 asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(tt[i & 7]) : "v"(cv[Q].z), "v"(cv[Q].w));
             } else if constexpr (op.kind == OP_ST) {
-                const unsigned vo = voff[i];
-                const u32x4 rsy = rsrcYe;
-                const unsigned so = soffY;
-                const float data = tt[i & 7];
-                asm volatile("buffer_store_dword %0, %1, %2, %3 offen nt" ::"v"(data), "v"(vo), "s"(rsy), "s"(so) : "memory");
+                store_row<8 * (i >> 2) + (i & 3)>(ta[i & 3], tt[i & 7], voff0, ldy4, rsrcYe, soffY);
             }
         };
 
@@ -392,9 +475,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             constexpr int DSLOT = (RSLOT + 3) & 3;                               // the slot refilled here: the previous body's
             const unsigned soff_here = std::min(soffW, img_bytes - SLOT);
             soffW += SLOT;
-            if constexpr (H == 0) {
-                soffY = (unsigned)(blk - 1) * 128u;
-            }
+            if constexpr (H == 0) soffY = (unsigned)(blk - 1) * 128u;
             static_for<0, 16>([&](auto JC) {
                 constexpr int J = decltype(JC)::value;
                 constexpr int G = 16 * H + J;                                    // sub-step of the block: strip registers 8 G ..
@@ -408,14 +489,14 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                 static_for<0, 3>([&](auto MC) {
                     constexpr int M = decltype(MC)::value, SG = 48 * H + 3 * J + M;
                     // lo.hi, hi.lo (small terms first), hi.hi
-                    if constexpr (M == 0) mfma_strip<8 * G + 4, (G == 0)>(acc[PAR], fr[G & 7][0]);
-                    else if constexpr (M == 1) mfma_strip<8 * G, false>(acc[PAR], fr[G & 7][1]);
-                    else mfma_strip<8 * G, false>(acc[PAR], fr[G & 7][0]);
+                    if constexpr (M == 0) mfma_strip<8 * G + 4, (G == 0)>(acc[PAR], fr[G % NSETS][0]);
+                    else if constexpr (M == 1) mfma_strip<8 * G, false>(acc[PAR], fr[G % NSETS][1]);
+                    else mfma_strip<8 * G, false>(acc[PAR], fr[G % NSETS][0]);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (M == 0) {
                         // fragments of the sub-step FD ahead (this slot, or the next one behind the barrier)
                         constexpr int JN = J + FD;
-                        constexpr int RS = JN < 16 ? RSLOT : NSLOT_R, JJ = JN & 15, GN = (G + FD) & 7;
+                        constexpr int RS = JN < 16 ? RSLOT : NSLOT_R, JJ = JN & 15, GN = (G + FD) % NSETS;
                         constexpr int OFFS = (RS & 1) * SLOT + JJ * 1024;
                         if constexpr (RS < 2) {
                             lds_read128<OFFS>(fr[GN][0], xa0);
@@ -431,7 +512,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(cv[PAR]) : "v"(cvoff), "s"(rsrcV), "s"(so) : "memory");
                     }
                     constexpr int dp = slot_piece(SG);
-                    if constexpr (dp >= 0) dma_piece(vP[dp], rsrcW, soff_here, lds0 + DSLOT * SLOT + wslot + dp * 1024);
+                    if constexpr (dp >= 0) dma_piece<DSLOT * SLOT + dp * 1024>(vP[dp], rsrcW, soff_here, ldsw);
                     static_for<PLAN.begin[SG], PLAN.begin[SG + 1]>([&](auto IC) {
                         __builtin_amdgcn_sched_barrier(0);
                         epi_item(std::integral_constant<int, Q>{}, IC, std::false_type{});
@@ -444,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         auto drain = [&](auto QC, int blk) {
-            STAMP(6);
+            STAMP(5);
             mfma_drain_nops();
             rsrcYe = rsrcY;
             soffY = (unsigned)blk * 128u;
@@ -468,9 +549,9 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         // segment end: nothing of this wave may still be in flight towards LDS or the fragment registers
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) asm volatile("" ::"v"(fr[s8][0]), "v"(fr[s8][1]));
-        __builtin_amdgcn_s_barrier();            // every wave is done with the ring before the next segment's prologue refills it
-        STAMP(7);
+        for (int s8 = 0; s8 < NSETS; ++s8) asm volatile("" ::"v"(fr[s8][0]), "v"(fr[s8][1]));
+        __builtin_amdgcn_s_barrier();            // every wave is done with the ring before the next segment's strip staging refills it
+        STAMP(6);
 #ifdef LAFF_FCS_TRACE
         ++trc_seg;
 #endif
@@ -522,7 +603,7 @@ __global__ __launch_bounds__(256) void fc_strip_pack_kernel(const float* __restr
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
-int g_fc_strip = 1;          // LAFF_FC_STRIP (read when a ctx is created): 0 = never, 1 = default
+int g_fc_strip = 1;          // LAFF_FC_STRIP (read when a ctx is created; the host's 0 = never take the strip form)
 
 size_t fc_strip_image_bytes(int D) { return (size_t)(D / 32) * (2 * SLOT) + (size_t)D * 16; }
 size_t fc_strip_vec_offset(int D) { return (size_t)(D / 32) * (2 * SLOT); }
