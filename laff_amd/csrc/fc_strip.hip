@@ -37,6 +37,13 @@
 #include "kernels.h"
 #include "strip_util.h"
 
+// 1: every body issues one L2 prefetch instruction over the next strip's rows.  Measured at the C4 group (tools/debug/trace_fc_strip.py):
+// the next segment's strip load drops from 13.2k to 8.4k cycles, but an instruction that touches 64 lines costs ~265 cycles of the
+// body it sits in (+8.5k per strip): a net loss, off.
+#ifndef LAFF_FCS_PREFETCH
+#define LAFF_FCS_PREFETCH 0
+#endif
+
 namespace laff {
 
 namespace {
@@ -60,13 +67,22 @@ static_assert(32 % NSETS == 0 && FD < NSETS, "the set of a sub-step must not dep
 constexpr int BAR_J = 16 - FD;                 // the body's barrier sits in front of this sub-step
 constexpr int NSLOT = 96;                      // MFMA issue slots of a column block: 2 bodies x 16 sub-steps x 3
 
-// ---- all 256 accumulator registers are named literally (the strip): nothing else lives there ---------------------------------------
-#define A16(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
-#define AGPR_ALL                                                                                                                   \
-    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", A16(1), A16(2), A16(3), A16(4), A16(5), A16(6), A16(7), A16(8), A16(9), \
-        A16(10), A16(11), A16(12), A16(13), A16(14), A16(15), A16(16), A16(17), A16(18), A16(19), A16(20), A16(21), A16(22), A16(23), \
-        A16(24), "a250", "a251", "a252", "a253", "a254", "a255"
-__device__ __forceinline__ void agpr_claim() { asm volatile("" ::: AGPR_ALL); }
+// ---- all 256 accumulator registers are named literally (the strip).  hipcc must not put anything of its own there (left alone it parks
+// long-lived values in a0.. when the 256 architectural registers get tight -- silently overwritten by the strip): 64 dummy quads are
+// defined in the accumulator file at kernel entry and "used" at its exit, so the allocator sees every one of them occupied throughout;
+// if registers run out it spills to scratch instead, which tools/debug/isa_audit.py reports. ----
+struct AgprHold { u32x4 q[64]; };
+#define HOLD16(OP, h, b)                                                                                                                  \
+    OP(h.q[b], h.q[b + 1], h.q[b + 2], h.q[b + 3], h.q[b + 4], h.q[b + 5], h.q[b + 6], h.q[b + 7], h.q[b + 8], h.q[b + 9], h.q[b + 10], h.q[b + 11], \
+       h.q[b + 12], h.q[b + 13], h.q[b + 14], h.q[b + 15])
+#define HOLD_DEF(x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, xa, xb, xc, xd, xe, xf)                                                            \
+    asm volatile("" : "=a"(x0), "=a"(x1), "=a"(x2), "=a"(x3), "=a"(x4), "=a"(x5), "=a"(x6), "=a"(x7), "=a"(x8), "=a"(x9), "=a"(xa), "=a"(xb), \
+                 "=a"(xc), "=a"(xd), "=a"(xe), "=a"(xf))
+#define HOLD_USE(x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, xa, xb, xc, xd, xe, xf)                                                            \
+    asm volatile("" ::"a"(x0), "a"(x1), "a"(x2), "a"(x3), "a"(x4), "a"(x5), "a"(x6), "a"(x7), "a"(x8), "a"(x9), "a"(xa), "a"(xb), "a"(xc),   \
+                 "a"(xd), "a"(xe), "a"(xf))
+__device__ __forceinline__ void agpr_hold_begin(AgprHold& h) { HOLD16(HOLD_DEF, h, 0); HOLD16(HOLD_DEF, h, 16); HOLD16(HOLD_DEF, h, 32); HOLD16(HOLD_DEF, h, 48); }
+__device__ __forceinline__ void agpr_hold_end(AgprHold& h) { HOLD16(HOLD_USE, h, 0); HOLD16(HOLD_USE, h, 16); HOLD16(HOLD_USE, h, 32); HOLD16(HOLD_USE, h, 48); }
 
 template <int R, int OFF>
 __device__ __forceinline__ void agpr_load4(const void* p) {            // a[R .. R + 3] <- 16 bytes at p + OFF
@@ -94,10 +110,11 @@ __device__ __forceinline__ void lds_read128(u32x4& d, unsigned addr) {
 }
 
 // one 1 KiB piece of the W stream, straight into LDS (lane L lands at M0 base + 16 L; the image is already in LDS order)
-template <int LDSOFF>
-__device__ __forceinline__ void dma_piece(unsigned voff, u32x4 rsrc, unsigned soff, unsigned m0base) {
-    asm volatile("s_add_i32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 ::"v"(voff), "s"(rsrc), "s"(soff), "s"(m0base), "n"(LDSOFF) : "memory", "scc");
+template <int LDSOFF, int SRCOFF>
+__device__ __forceinline__ void dma_piece(unsigned lane16, u32x4 rsrc, unsigned soff, unsigned m0base) {
+    unsigned t;
+    asm volatile("v_add_u32 %0, %6, %1\n\ts_add_i32 m0, %4, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                 : "=&v"(t) : "v"(lane16), "s"(rsrc), "s"(soff), "s"(m0base), "n"(LDSOFF), "n"(SRCOFF) : "memory", "scc");
 }
 
 // 1 KiB of input rows straight into LDS (lane L lands at M0 base + LDSOFF + 16 L): scalar base + per-lane 32-bit offset.  (No
@@ -128,6 +145,48 @@ __device__ __forceinline__ int split_exponent(float m) {
     return max(be - 127, -100);
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+// L2 prefetch of the NEXT strip: one dword per lane, 64 different 128-byte lines per instruction (line 64 i + lane of this wave's 512:
+// row 4 i + (lane >> 4), segment lane & 15); the value is never used.  (Rows beyond the matrix touch the last row.)  `sink` is
+// read-write so that it stays ONE live register from the first prefetch to the segment's end: as a plain output every statement's
+// destination is dead at once for hipcc, which hands the register to something else while the load is still in flight.
+__device__ __forceinline__ void prefetch_lines(unsigned& sink, unsigned v_row, unsigned v_seg128, unsigned s_4i, unsigned s_maxrow, unsigned s_ldx4,
+                                               unsigned long long base) {
+    unsigned t;
+    asm volatile("v_add_u32 %1, %4, %2\n\tv_min_u32 %1, %5, %1\n\tv_mad_u32_u24 %1, %1, %6, %3\n\tglobal_load_dword %0, %1, %7"
+                 : "+v"(sink), "=&v"(t) : "v"(v_row), "v"(v_seg128), "s"(s_4i), "s"(s_maxrow), "s"(s_ldx4), "s"(base) : "memory");
+}
+// one raw chunk (two quads from the staging read-back) -> a[R .. R + 7], its eight values folded into the two running row maxima
+template <int R>
+__device__ __forceinline__ void stash_chunk(const u32x4& q0, const u32x4& q1, float& m0, float& m1) {
+    asm volatile("v_max3_f32 %0, |%2|, |%3|, %0\n\tv_max3_f32 %1, |%4|, |%5|, %1\n\tv_max3_f32 %0, |%6|, |%7|, %0\n\tv_max3_f32 %1, |%8|, |%9|, %1\n\t"
+                 "v_accvgpr_write_b32 a[%c10+0], %2\n\tv_accvgpr_write_b32 a[%c10+1], %3\n\tv_accvgpr_write_b32 a[%c10+2], %4\n\t"
+                 "v_accvgpr_write_b32 a[%c10+3], %5\n\tv_accvgpr_write_b32 a[%c10+4], %6\n\tv_accvgpr_write_b32 a[%c10+5], %7\n\t"
+                 "v_accvgpr_write_b32 a[%c10+6], %8\n\tv_accvgpr_write_b32 a[%c10+7], %9"
+                 : "+v"(m0), "+v"(m1) : "v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w), "n"(R));
+}
+// a[R .. R + 7] (eight fp32: k = 16 g + 4 hh + {0..3}, + 8) -> a[R .. R + 3] = their fp16 hi halves, a[R + 4 .. R + 7] = the lo halves.
+//   hi = f16(x s) (x s is exact: s is a power of two), residual x s - hi exact in fp32, lo = f16(residual): split_rows_kernel's
+//   arithmetic (fuse.hip), as one statement with the four pairs' chains interleaved (a dependent VALU pair costs 7 cycles, not 4)
+template <int R>
+__device__ __forceinline__ void convert_chunk_inplace(float s) {
+    float x0, x1, x2, x3, x4, x5, x6, x7;
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    asm volatile(
+        "v_accvgpr_read_b32 %0, a[%c17+0]\n\tv_accvgpr_read_b32 %1, a[%c17+1]\n\tv_accvgpr_read_b32 %2, a[%c17+2]\n\tv_accvgpr_read_b32 %3, a[%c17+3]\n\t"
+        "v_accvgpr_read_b32 %4, a[%c17+4]\n\tv_accvgpr_read_b32 %5, a[%c17+5]\n\tv_accvgpr_read_b32 %6, a[%c17+6]\n\tv_accvgpr_read_b32 %7, a[%c17+7]\n\t"
+        "v_fma_mixlo_f16 %8, %0, %16, 0\n\tv_fma_mixlo_f16 %9, %2, %16, 0\n\tv_fma_mixlo_f16 %10, %4, %16, 0\n\tv_fma_mixlo_f16 %11, %6, %16, 0\n\t"
+        "v_fma_mixhi_f16 %8, %1, %16, 0\n\tv_fma_mixhi_f16 %9, %3, %16, 0\n\tv_fma_mixhi_f16 %10, %5, %16, 0\n\tv_fma_mixhi_f16 %11, %7, %16, 0\n\t"
+        "v_fma_mix_f32 %0, %0, %16, -%8 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %2, %2, %16, -%9 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %4, %4, %16, -%10 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %6, %6, %16, -%11 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %1, %1, %16, -%8 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %3, %3, %16, -%9 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %5, %5, %16, -%10 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mix_f32 %7, %7, %16, -%11 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_accvgpr_write_b32 a[%c17+0], %8\n\tv_accvgpr_write_b32 a[%c17+1], %9\n\tv_accvgpr_write_b32 a[%c17+2], %10\n\tv_accvgpr_write_b32 a[%c17+3], %11\n\t"
+        "v_cvt_pk_f16_f32 %12, %0, %1\n\tv_cvt_pk_f16_f32 %13, %2, %3\n\tv_cvt_pk_f16_f32 %14, %4, %5\n\tv_cvt_pk_f16_f32 %15, %6, %7\n\t"
+        "v_accvgpr_write_b32 a[%c17+4], %12\n\tv_accvgpr_write_b32 a[%c17+5], %13\n\tv_accvgpr_write_b32 a[%c17+6], %14\n\tv_accvgpr_write_b32 a[%c17+7], %15"
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7), "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3),
+          "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(s), "n"(R));
+}
 __device__ __forceinline__ void absmax3(float& m, float x, float y) { asm volatile("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(x), "v"(y)); }
 // hi = f16(x s) for two values (x s is exact: s is a power of two), the residuals x s - hi (exact in fp32) replace x, lo = f16(residual):
 // the arithmetic of split_rows_kernel (fuse.hip)
@@ -176,6 +235,8 @@ constexpr EpiStream make_stream() {
 //   * in front of sub-step BAR_J: counted vmcnt (this wave's pieces of the next slot have landed) + s_barrier (everybody's have, and
 //     everybody is done with the previous slot, which the pieces issued right behind the barrier refill -- 4 slots: 3 ahead);
 //   * (BAR_J .. BAR_J + 3, M = 1, 2): the 8 DMA pieces;  (H = 0, J = 0, M = 1): this block's four lane constants (one 16-byte load);
+//   * (J = 14, M = 1): one L2 PREFETCH instruction over the NEXT strip's rows (64 lines; the last ten bodies of a strip walk its 512
+//     lines per wave, earlier ones re-touch the first 64): the strip load of the next segment then runs at L2 latency;
 //   * everything else: the epilogue stream of the previous block, spread evenly (cost-weighted).  It starts behind the third MFMA
 //     of the block (the previous block's last MFMA has retired by then) and ends before the block does.
 constexpr int slot_piece(int sg) {
@@ -184,6 +245,7 @@ constexpr int slot_piece(int sg) {
     return -1;
 }
 constexpr bool slot_cvload(int sg) { return sg == 1; }
+constexpr bool slot_prefetch(int sg) { return sg % 48 == 3 * 14 + 1; }      // (J = 14, M = 1): behind the body's DMA pieces
 struct Plan {
     short begin[NSLOT + 1];
     short vm_bar[2];      // vmcnt operand at the barrier of body H
@@ -216,6 +278,7 @@ constexpr Plan make_plan() {
             const int H = sg / 48, J = (sg % 48) / 3, M = sg % 3;
             if (J == BAR_J && M == 0) bar_at[blk][H] = vm_n;
             if (slot_cvload(sg)) cv_ord[blk] = ++vm_n;
+            if (slot_prefetch(sg) && LAFF_FCS_PREFETCH) ++vm_n;
             if (slot_piece(sg) >= 0) { ++vm_n; last_piece[blk][H] = vm_n; }
             for (int i = p.begin[sg]; i < p.begin[sg + 1]; ++i) {
                 if (st.op[i].kind == OP_WAITCV) waitcv_at[blk] = vm_n;
@@ -234,7 +297,8 @@ constexpr Plan make_plan() {
 template <int ACTK>
 __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    agpr_claim();
+    AgprHold hold;
+    agpr_hold_begin(hold);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n31 = lane & 31, hh = lane >> 5;
@@ -255,15 +319,15 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
     // per-lane constants of the loops
     unsigned lane16 = (unsigned)lane * 16u;
     asm volatile("" : "+v"(lane16));
-    unsigned vP[PIECES];                                    // source offsets of the 8 pieces of a slot: piece P, lane L -> 1024 P + 16 L
-#pragma unroll
-    for (int P = 0; P < PIECES; ++P) { vP[P] = lane16 + 1024u * P; asm volatile("" : "+v"(vP[P])); }
     const unsigned xa0 = lds0 + lane16, xa1 = lds0 + lane16 + 2u * SLOT;      // fragment addresses: ring slots 0, 1 | 2, 3
     const unsigned wslot = (unsigned)wave * (PIECES * 1024u);                   // this wave's 8 KiB of a slot (LDS and source offset)
     const unsigned ldsw = pin_s(lds0 + wslot);                                  // LDS address of this wave's 8 KiB of ring slot 0
     const unsigned stg = pin_s(lds0 + (unsigned)wave * (unsigned)SLOT);         // strip staging: this wave's QUARTER of the (idle) ring
     const unsigned cvoff = (unsigned)n31 * 16u;
     float* const rsb = (float*)(smem + RS_OFF) + wave * 32;                     // this wave's 32 row scales (wave-private exchange)
+    unsigned pf_row = (unsigned)wave * 32u + ((unsigned)lane >> 4), pf_seg128 = ((unsigned)lane & 15u) * 128u;       // prefetch: lane -> (row, segment)
+    asm volatile("" : "+v"(pf_row), "+v"(pf_seg128));
+    unsigned pf_sink = 0u;
     const unsigned m0_keep = m0_get();
 #ifdef LAFF_FCS_TRACE
     // debug build: cycle stamps of wave 0 -- per segment s (up to 8): base 8 s: +0 start, +1 strip in the registers (raw), +2 row maxima,
@@ -289,6 +353,19 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
 #ifdef LAFF_FCS_TRACE
         if (trc && tid == 0 && trc_seg < 8) trc[64 + trc_seg] = (unsigned long long)n;
 #endif
+        // the strip this segment's bodies prefetch: the next segment's (this one's own when there is none: valid memory, harmless)
+        const bool has_next = u0 < u1;
+        int p2 = p, strip2 = strip;
+        if (has_next) {
+            p2 = 0;
+            while (p2 + 1 < count && u0 >= a.p[p2 + 1].unit0) ++p2;
+            p2 = __builtin_amdgcn_readfirstlane(p2);
+            strip2 = __builtin_amdgcn_readfirstlane((u0 - a.p[p2].unit0) / nblk);
+        }
+        const unsigned pf_ldx4 = pin_s((unsigned)a.p[p2].ldx * 4u);
+        const unsigned pf_maxrow = pin_s((unsigned)(a.p[p2].N - 1 - strip2 * FR));
+        const unsigned long long pf_base = pin_s((unsigned long long)a.p[p2].X + (unsigned long long)(strip2 * FR) * (unsigned)a.p[p2].ldx * 4ull);
+        int pf_i = std::min(10 - 2 * n, 0);              // body k prefetches line set clamp(k + pf_i, 0, 7): the last ten bodies walk all eight
         const int N = pin_s(a.p[p].N), ldx = pin_s(a.p[p].ldx), ldy = pin_s(a.p[p].ldy);
         const unsigned long long pX = pin_s((unsigned long long)a.p[p].X), pW = pin_s((unsigned long long)a.p[p].img);
         const unsigned long long pVec = pin_s((unsigned long long)a.p[p].vec), pY = pin_s((unsigned long long)a.p[p].Y);
@@ -301,6 +378,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         unsigned ta[4] = {0, 0, 0, 0};
         f32x4 cv[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 
+        int e_row = 0;                   // exponent of this lane's row maximum: scale 2^(9 - e) in, 2^(e - 9) out
         // ---- the strip: this wave's 32 rows x 512 fp32 -> a[0:255].  The rows come in by LDS-DMA, 2 rows x 512 contiguous bytes per
         // instruction (direct 16-byte loads in the fragment layout touch 32 rows per instruction and run at a fifth of the rate), in four
         // rounds of one K quarter each (16 KiB) through two buffers in this wave's quarter of the idle ring; the source piece is
@@ -329,13 +407,26 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                     dma_rows<(q & 1) * 16384 + t * 1024>(sv[t], qbase, stg);
                 });
             };
+            float m0 = 0.f, m1 = 0.f;                  // running maxima of |x| over this lane's half of its row
+            u32x4 rq[16];
             auto read_round = [&](auto QC) {
+                // the round's 8 chunks: 16 reads into registers, then each chunk goes to its accumulator registers (raw) while its
+                // values are folded into the row maxima -- VALU work in the shadow of the next round's flight
                 constexpr int q = decltype(QC)::value;
                 static_for<0, 8>([&](auto CC) {
-                    constexpr int cc = decltype(CC)::value, c = 8 * q + cc;
+                    constexpr int cc = decltype(CC)::value;
                     constexpr int IMM = (q & 1) * 16384 + 256 * (cc >> 2);
-                    lds_to_agpr<8 * c, IMM>(XA[2 * (cc & 3)]);
-                    lds_to_agpr<8 * c + 4, IMM>(XA[2 * (cc & 3) + 1]);
+                    lds_read128<IMM>(rq[2 * cc], XA[2 * (cc & 3)]);
+                    lds_read128<IMM>(rq[2 * cc + 1], XA[2 * (cc & 3) + 1]);
+                });
+                wait_lgkm<0>();
+                static_for<0, 16>([&](auto IC) { pin_v(rq[decltype(IC)::value]); });
+            };
+            auto stash_round = [&](auto QC) {
+                constexpr int q = decltype(QC)::value;
+                static_for<0, 8>([&](auto CC) {
+                    constexpr int cc = decltype(CC)::value;
+                    stash_chunk<8 * (8 * q + cc)>(rq[2 * cc], rq[2 * cc + 1], m0, m1);
                 });
             };
             using Q0 = std::integral_constant<int, 0>;
@@ -345,18 +436,16 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             issue_round(Q0{});
             issue_round(Q1{});
             wait_vm<16>();
-            read_round(Q0{});
-            wait_lgkm<0>();
-            issue_round(Q2{});
+            read_round(Q0{}); issue_round(Q2{}); stash_round(Q0{});
             wait_vm<16>();
-            read_round(Q1{});
-            wait_lgkm<0>();
-            issue_round(Q3{});
+            read_round(Q1{}); issue_round(Q3{}); stash_round(Q1{});
             wait_vm<16>();
-            read_round(Q2{});
+            read_round(Q2{}); stash_round(Q2{});
             wait_vm<0>();
-            read_round(Q3{});
-            wait_lgkm<0>();
+            read_round(Q3{}); stash_round(Q3{});
+            float m = fmaxf(m0, m1);
+            m = fmaxf(m, __shfl_xor(m, 32));           // a row lives in lanes l and l + 32
+            e_row = split_exponent(m);
         }
         __builtin_amdgcn_s_barrier();            // every wave has emptied its staging quarter: the ring may fill
         asm volatile("" ::: "memory");
@@ -370,42 +459,24 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             constexpr int s = decltype(SC)::value;
             static_for<0, PIECES>([&](auto PC) {
                 constexpr int P = decltype(PC)::value;
-                dma_piece<s * SLOT + P * 1024>(vP[P], rsrcW, std::min(soffW, img_bytes - SLOT), ldsw);
+                dma_piece<s * SLOT + P * 1024, P * 1024>(lane16, rsrcW, std::min(soffW, img_bytes - SLOT), ldsw);
             });
             soffW += SLOT;
         });
 
-        // ---- row maxima (a row lives in lanes l and l + 32), scale, in-place conversion to the hi / lo fragments ----
+        // ---- the raw strip is converted in place ----
+        STAMP(2);
         {
-            float m0 = 0.f, m1 = 0.f;
-            static_for<0, 64>([&](auto IC) {
-                constexpr int i = decltype(IC)::value;
-                const float x0 = agpr_read<4 * i>(), x1 = agpr_read<4 * i + 1>(), x2 = agpr_read<4 * i + 2>(), x3 = agpr_read<4 * i + 3>();
-                absmax3(m0, x0, x1);
-                absmax3(m1, x2, x3);
-            });
-            float m = fmaxf(m0, m1);
-            m = fmaxf(m, __shfl_xor(m, 32));
-            const int e = split_exponent(m);
-            const float s = pow2f(9 - e);
-            STAMP(2);
+            const float s = pow2f(9 - e_row);
+            asm volatile("s_nop 1" ::: "memory");
             // sub-step g: hi <- a[8 g .. 8 g + 3], lo <- a[8 g + 4 .. 8 g + 7]; halves e = 0 .. 7 <-> raw registers 8 g + e
-            static_for<0, 32>([&](auto GC) {
-                constexpr int g = decltype(GC)::value;
-                float x[8];
-                static_for<0, 8>([&](auto EC) { constexpr int q = decltype(EC)::value; x[q] = agpr_read<8 * g + q>(); });
-                unsigned hi[4], lo[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) split_pair(x[2 * q], x[2 * q + 1], s, hi[q], lo[q]);
-                static_for<0, 4>([&](auto QC) {
-                    constexpr int q = decltype(QC)::value;
-                    agpr_write<8 * g + q>(hi[q]);
-                    agpr_write<8 * g + 4 + q>(lo[q]);
-                });
-            });
-            STAMP(3);
+            static_for<0, 32>([&](auto GC) { convert_chunk_inplace<8 * decltype(GC)::value>(s); });
+        }
+        asm volatile("s_nop 3" ::: "memory");            // v_accvgpr_write -> MFMA reading it
+        STAMP(3);
+        {
             // the epilogue's row scales: lane (n31, hh) needs those of rows 8 q + 4 hh + e -- through LDS (wave-private)
-            if (hh == 0) rsb[n31] = pow2f(e - 9);
+            if (hh == 0) rsb[n31] = pow2f(e_row - 9);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -511,8 +582,12 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                         const unsigned so = (unsigned)blk * 512u;
                         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(cv[PAR]) : "v"(cvoff), "s"(rsrcV), "s"(so) : "memory");
                     }
+                    if constexpr (slot_prefetch(SG) && LAFF_FCS_PREFETCH) {
+                        prefetch_lines(pf_sink, pf_row, pf_seg128, (unsigned)(4 * std::min(std::max(pf_i, 0), 7)), pf_maxrow, pf_ldx4, pf_base);
+                        ++pf_i;
+                    }
                     constexpr int dp = slot_piece(SG);
-                    if constexpr (dp >= 0) dma_piece<DSLOT * SLOT + dp * 1024>(vP[dp], rsrcW, soff_here, ldsw);
+                    if constexpr (dp >= 0) dma_piece<DSLOT * SLOT + dp * 1024, dp * 1024>(lane16, rsrcW, soff_here, ldsw);
                     static_for<PLAN.begin[SG], PLAN.begin[SG + 1]>([&](auto IC) {
                         __builtin_amdgcn_sched_barrier(0);
                         epi_item(std::integral_constant<int, Q>{}, IC, std::false_type{});
@@ -550,6 +625,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int s8 = 0; s8 < NSETS; ++s8) asm volatile("" ::"v"(fr[s8][0]), "v"(fr[s8][1]));
+        asm volatile("" ::"v"(pf_sink));
         __builtin_amdgcn_s_barrier();            // every wave is done with the ring before the next segment's strip staging refills it
         STAMP(6);
 #ifdef LAFF_FCS_TRACE
@@ -557,6 +633,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
 #endif
     }
     m0_set(m0_keep);
+    agpr_hold_end(hold);
 #undef STAMP
 }
 

@@ -105,3 +105,31 @@ def test_product_never_imports_the_oracle():
         assert 'import oracle' not in src and 'from oracle' not in src and 'laff_oracle' not in src, f
     for f in glob.glob(os.path.join(ROOT, 'laff_amd', 'csrc', '*')):
         assert 'oracle' not in open(f).read().lower(), f
+
+
+def test_fc_strip_kernels_keep_out_of_the_accumulator_registers(tmp_path):
+    """fc_strip.hip names all 256 accumulator registers literally (the stationary strip).  hipcc must not have put anything of its own
+    there -- neither a parked value (v_accvgpr_* outside the asm statements) nor a spill -- and must not have gone to scratch: compile
+    the file with -save-temps and audit the ISA of its kernels (tools/debug/isa_audit.py)."""
+    import re
+    import subprocess
+    import sys
+    from laff_amd import build
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'debug'))
+    import isa_audit
+    src = os.path.join(build.CSRC, 'fc_strip.hip')
+    r = subprocess.run([build.hipcc()] + build.FLAGS + ['-save-temps=obj', '-c', src, '-o', str(tmp_path / 'fc_strip.o')],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    asm = [str(tmp_path / f) for f in os.listdir(tmp_path) if f.endswith('gfx950.s')]
+    assert len(asm) == 1
+    stats = isa_audit.audit(asm[0], 'fc_strip_kernel', quiet=True)
+    assert len(stats) == 3                                    # the three epilogue kinds
+    for name, st in stats.items():
+        assert st['acc_outside'] == 0 and st['scratch'] == 0, (name, st)
+        assert st['mfma'] == 4 * 48, (name, st)
+    text = open(asm[0]).read()
+    for name in stats:
+        meta = text[text.index('.name:           ' + name):]
+        assert int(re.search(r'\.vgpr_spill_count: (\d+)', meta).group(1)) == 0
+        assert int(re.search(r'\.sgpr_spill_count: (\d+)', meta).group(1)) == 0

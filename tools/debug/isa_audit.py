@@ -7,7 +7,7 @@ loads and s_waitcnt (inside a hand-counted loop they break the counting), scratc
 import sys
 
 
-def audit(path, want=None):
+def audit(path, want=None, quiet=False):
     fn = None
     stats = {}
     inasm = False
@@ -45,9 +45,11 @@ def audit(path, want=None):
                 st['snop_outside'] += 1
             if t.startswith('v_mov_b32'):
                 st['vmov_outside'] += 1
-    for k, v in stats.items():
-        if want is None or want in k:
+    out = {k: v for k, v in stats.items() if want is None or want in k}
+    if not quiet:
+        for k, v in out.items():
             print(k[:70], v)
+    return out
 
 
 if __name__ == '__main__':
