@@ -221,7 +221,7 @@ def dryrun_main(args):
     of RCCL, the oracle-backed stand-in of the per-rank kernels (tests/dist_util.py) on a toy problem.  Not a measurement."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from dist_util import OracleBackend, problem
-    from laff_amd.dist import evaluate_sharded, evaluate_sharded_by_text, shard_bounds
+    from laff_amd.dist import evaluate_sharded, evaluate_sharded_by_text, evaluate_sharded_v16, gathered_bytes, shard_bounds
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -234,7 +234,7 @@ def dryrun_main(args):
     be = OracleBackend(Wt, Wv)
     vis_l, txt_l, gt_t = {'x': torch.from_numpy(xv[v0:v1])}, {'x': torch.from_numpy(xt[t0:t1])}, torch.from_numpy(gt)
     out = {}
-    for kind, fn in (('video', evaluate_sharded), ('text', evaluate_sharded_by_text)):
+    for kind, fn in (('video', evaluate_sharded), ('text', evaluate_sharded_by_text), ('video16', evaluate_sharded_v16)):
         for _ in range(max(1, args.warmup)):
             res = fn(be, vis_l, txt_l, gt_t, Nt, Nv, 1)
         if world > 1:
@@ -259,6 +259,10 @@ def dryrun_main(args):
                            'shard': 'video', 'backend': 'gloo'},
                 'alt_shard': {'shard': 'text', 'ms_per_step': 1e3 * out['text'][0] / args.steps,
                               'ranks_equal': bool(torch.equal(out['text'][1]['ranks'], res['ranks']))},
+                'alt_shards': [{'shard': k, 'ms_per_step': 1e3 * out[k][0] / args.steps,
+                                'ranks_equal': bool(torch.equal(out[k][1]['ranks'], res['ranks'])),
+                                'gathered_bytes_per_step': gathered_bytes(k, Nt, Nv, Wt.shape[1], world, 4096)} for k in ('text', 'video16')],
+                'gathered_bytes_per_step': gathered_bytes('video', Nt, Nv, Wt.shape[1], world),
                 'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3]}, 'collective_ms': None,
                 'roofline': None, 'cpu_baseline': None}
         os.write(json_fd, (json.dumps(line) + '\n').encode())
@@ -276,11 +280,12 @@ def main():
     ap.add_argument('--fc-precision', default='fp16x3', help="FC projections: fp32 (fp32 MFMA) | fp16x3 (exact fp16 hi/lo split)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of HIP-graph replays')
-    ap.add_argument('--shard', default='video', choices=['auto', 'video', 'text'],
+    ap.add_argument('--shard', default='video', choices=['auto', 'video', 'text', 'video16'],
                     help="N > 1 decomposition of the headline number: 'video' (default; BASELINE.json: video-row shards, all-gather of "
                          "the text embeddings, two small all-reduces), 'text' (text-row shards, all-gather of the video embeddings, no "
-                         "all-reduce) or 'auto' = the one that gathers fewer rows (laff_amd.dist.choose_sharding).  The other scheme is "
-                         "timed too and reported beside it (alt_shard)")
+                         "all-reduce), 'video16' (video-row shards with the 16-bit text operand + the fp32 video rows gathered and the in-band "
+                         "pairs sent to the owner of their text row) or 'auto' = 'video' / 'text', whichever gathers fewer rows "
+                         "(laff_amd.dist.choose_sharding).  The other schemes are timed too and reported beside it (alt_shards)")
     ap.add_argument('--two-streams', action='store_true', help='single GPU: alternate the two captured steps between two streams')
     ap.add_argument('--no-extra-modes', action='store_true', help='skip the sustained loop and the count-only mode (profiling runs)')
     ap.add_argument('--sustain-seconds', type=float, default=2.0, help='extra untimed-by-the-driver loop reporting the sustained rate')
@@ -323,7 +328,8 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     from laff_amd import synth
-    from laff_amd.dist import HipBackend, check_metrics_flag, choose_sharding, evaluate_sharded, evaluate_sharded_by_text, shard_bounds
+    from laff_amd.dist import (HipBackend, check_metrics_flag, choose_sharding, evaluate_sharded, evaluate_sharded_by_text,
+                               evaluate_sharded_v16, gathered_bytes, shard_bounds)
     import laff_amd.model.model as M
     M.FC_PRECISION = args.fc_precision
     Nt, Nv, heads, d, frames = synth.WORKLOADS[args.workload]
@@ -359,6 +365,10 @@ def main():
             return evaluate_sharded_by_text(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer, want_scores=want_scores,
                                             metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
                                             force_collectives=force_dist, finish_tag=str(slot))
+        if (kind or shard) == 'video16' and distributed:
+            return evaluate_sharded_v16(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer, want_scores=want_scores,
+                                        metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
+                                        force_collectives=force_dist, finish_tag=str(slot))
         return evaluate_sharded(backend, vis_l, txt_l, gt, Nt, Nv, heads, timer=timer, want_scores=want_scores,
                                 metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
                                 force_collectives=force_dist, finish_tag=str(slot))
@@ -547,26 +557,30 @@ def main():
         final_metrics = res['metrics']
         prof_steps = args.steps
 
-    # the other N > 1 decomposition, timed the same way, reported beside the headline one
-    alt = None
+    # the other N > 1 decompositions, timed the same way, reported beside the headline one
+    alt, alts = None, []
     if distributed:
-        other = 'text' if shard == 'video' else 'video'
-        try:
-            r2, s2 = None, {}
-            if runner is not None:
-                from laff_amd.dist import GraphRunner
-                r2 = GraphRunner()
-                for slot in (0, 1):
-                    step(False, async_metrics=True, runner=r2, state=s2, slot=slot, kind=other)
-                    torch.cuda.synchronize()
-            else:
-                step(False, kind=other)
-            el2 = dist_loop(other, r2, s2)
-            alt = {'shard': other, 'ms_per_step': 1e3 * el2 / args.steps, 'value': float(Nt) * Nv * args.steps / el2,
-                   'R@1': float(pins[(args.steps - 1) % 2][0]) if r2 is not None else None}
-            del r2, s2
-        except Exception as e:  # noqa: BLE001  (every rank takes the same path: the collectives stay matched)
-            alt = {'shard': other, 'error': str(e)}
+        K_emb = heads * d
+        for other in [k for k in ('video', 'text', 'video16') if k != shard and (k != 'video16' or backend.v16_ok())]:
+            try:
+                r2, s2 = None, {}
+                if runner is not None:
+                    from laff_amd.dist import GraphRunner
+                    r2 = GraphRunner()
+                    for slot in (0, 1):
+                        step(False, async_metrics=True, runner=r2, state=s2, slot=slot, kind=other)
+                        torch.cuda.synchronize()
+                else:
+                    step(False, kind=other)
+                el2 = dist_loop(other, r2, s2)
+                one = {'shard': other, 'ms_per_step': 1e3 * el2 / args.steps, 'value': float(Nt) * Nv * args.steps / el2,
+                       'R@1': float(pins[(args.steps - 1) % 2][0]) if r2 is not None else None,
+                       'gathered_bytes_per_step': gathered_bytes(other, Nt, Nv, K_emb, world, max(4096, (32 * Nt // (world * world) + 3) & ~3))}
+                del r2, s2
+            except Exception as e:  # noqa: BLE001  (every rank takes the same path: the collectives stay matched)
+                one = {'shard': other, 'error': str(e)}
+            alts.append(one)
+        alt = alts[0] if alts else None
 
     sustained, no_scores = None, None
     if graph is not None and world == 1 and not distributed and not args.no_extra_modes:
@@ -745,9 +759,11 @@ def main():
                            'video %s (no FC: %s) + text %s (no FC: %s, bow sparse CSR)' % (spec['vid'], spec['vis_no_transform'],
                                                                                          spec['txt'], spec['txt_no_transform']),
                            heads, d),
-                       'parallelism': (('video-row shards x%d, all-gather of the fp32 text embeddings, all-reduce MAX(s_gt) + SUM(counts)'
-                                        if shard == 'video' else
-                                        'text-row shards x%d, all-gather of the fp32 video embeddings + of the ranks') % world)
+                       'parallelism': ({'video': 'video-row shards x%d, all-gather of the fp32 text embeddings, all-reduce MAX(s_gt) + SUM(counts)',
+                                        'text': 'text-row shards x%d, all-gather of the fp32 video embeddings + of the ranks',
+                                        'video16': 'video-row shards x%d, all-gather of the 16-bit text operand + of the fp32 video embeddings + of '
+                                                   '{s_gt64, band}, all-to-all of the in-band pairs to the text owners, all-reduce SUM(counts), '
+                                                   'all-gather of the ranks'}[shard] % world)
                        if distributed else 'single GPU',
                        'force_dist': bool(force_dist), 'shard': shard if distributed else None,
                        'scores': 'fp32 S materialised in HBM (count-only mode reported under no_scores_mode)',
@@ -756,9 +772,13 @@ def main():
             'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6],
                         'vs_strict_similarity': agreement},
             # per-step time this rank's stream spent in / waiting on each collective (eager pass, HIP events around the call)
-            'collective_ms': ({k: round(stages[k], 4) for k in ('all_gather_wait', 'allreduce_s_gt', 'allreduce_count', 'allgather_ranks')
-                               if k in stages} if distributed else None),
+            'collective_ms': ({k: round(stages[k], 4) for k in ('all_gather_wait', 'allreduce_s_gt', 'allreduce_count', 'allgather_ranks',
+                                                                  'allgather_sgt_band', 'alltoall_pairs') if k in stages} if distributed else None),
+            # payload bytes that reach one rank per step from the others, by collective (laff_amd.dist.gathered_bytes)
+            'gathered_bytes_per_step': (gathered_bytes(shard, Nt, Nv, heads * d, world, max(4096, (32 * Nt // (world * world) + 3) & ~3))
+                                        if distributed else None),
             'alt_shard': alt,
+            'alt_shards': alts if distributed else None,
             'stages_ms_eager_pass': {k: round(v, 4) for k, v in stages.items()},   # host-issued launches with events: longer than a graph step
             'sustained': sustained,
             'no_scores_mode': no_scores,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 16
+#define LAFF_ABI_VERSION 17
 
 enum {
     LAFF_OK = 0,
@@ -279,6 +279,24 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
  * laff_sim_gemm adds into (saves a fill launch). */
 int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
                     const int* gt_col, int col0, float* s_gt, int* zero_count);
+
+/* laff_rank_prepare for ONE side of a sharded pass (laff_amd/dist.py 'video16': the 16-bit text operand is what is all-gathered, the
+ * fp32 text rows stay with their owner):
+ *   sides = 1, text rows : s_gt64 [Nt] = the exact score of every text against Ev[gt_col - col0] (-inf outside [0, Nv)), band_t [Nt],
+ *                          count cleared, list header cleared.  Ev = the fp32 video rows present (V, band_v untouched, may be NULL);
+ *   sides = 2, video rows: band_v [((Nv + 3) & ~3) + ceil(Nv / 64)] (Et, T, gt_col, s_gt64, band_t untouched, may be NULL). */
+int laff_rank_prepare_part(laff_ctx* ctx, int sides, const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H,
+                           int d, int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t, float* band_v,
+                           int* zero_count, unsigned* pairs);
+
+/* The listed pairs of a video shard's laff_sim_gemm_banded, exported to the owners of the TEXT rows instead of re-scored here (the exact
+ * re-score needs the fp32 text row).  bounds [world + 1] (device): owner o holds text rows [bounds[o], bounds[o + 1]).  out: `world`
+ * buckets of `cap` slots {row - bounds[o], col + col0}, unused slots 0xffffffff (the call fills them); fill [world + 1]: pairs per
+ * bucket, [world] = 1 if a bucket overflowed (then count[0] is poisoned like an overflowing list).  Behind a 4-word header
+ * {0, 0, n_slots, 4} any concatenation of buckets is a list laff_rank_resolve reads.  S (optional): the ground-truth entries take
+ * the exact score, as laff_rank_resolve would write them.  predictor.py:232-244 is the loop this pipeline replaces. */
+int laff_rank_export_pairs(laff_ctx* ctx, const double* s_gt64, int* count, float* S, int lds, int Nv, unsigned* pairs, unsigned pair_cap,
+                           const int* bounds /*device*/, int world, int col0, unsigned* out, unsigned cap, unsigned* fill);
 
 /* ---- a12 made EXACT on a reduced-precision GEMM ------------------------------------------------------------------------------
  * The reference ranks come from fp32 scores (predictor.py:232-244 on model/model.py:1003-1016).  A 16-bit MFMA pass keeps the

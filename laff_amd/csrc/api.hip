@@ -705,7 +705,39 @@ int laff_rank_prepare(laff_ctx* ctx, const float* Et, const float* Ev, const voi
         return fail(LAFF_E_ALIGN, "laff_rank_prepare: embeddings and operands must be 16-byte aligned");
     DeviceGuard g(ctx->device);
     HIP_TRY(laff::launch_rank_prepare(Et, Ev, T, V, Nt, Nv, H, d, precision, prescale, gt_col, col0, s_gt64, band_t, band_v, zero_count,
-                                      pairs, ctx->stream));
+                                      pairs, 3, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_rank_prepare_part(laff_ctx* ctx, int sides, const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H,
+                           int d, int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t, float* band_v,
+                           int* zero_count, unsigned* pairs) {
+    CHECK_CTX(ctx);
+    if (sides != 1 && sides != 2) return fail(LAFF_E_ARG, "laff_rank_prepare_part: sides must be 1 (text rows) or 2 (video rows)");
+    if ((sides == 1 && Nt == 0) || (sides == 2 && Nv == 0)) return LAFF_OK;
+    if (sides == 1 && (!Et || !T || !gt_col || !s_gt64 || !band_t || (Nv > 0 && !Ev))) return fail(LAFF_E_ARG, "laff_rank_prepare_part: null argument (text side)");
+    if (sides == 2 && (!Ev || !V || !band_v)) return fail(LAFF_E_ARG, "laff_rank_prepare_part: null argument (video side)");
+    if (precision < LAFF_PREC_FP32 || precision > LAFF_PREC_BF16X3) return fail(LAFF_E_ARG, "laff_rank_prepare_part: bad precision %d", precision);
+    if (Nt < 0 || Nv < 0 || H < 1 || d < 4 || (d & 3)) return fail(LAFF_E_SHAPE, "laff_rank_prepare_part: need H >= 1, d %% 4 == 0 (Nt=%d Nv=%d H=%d d=%d)", Nt, Nv, H, d);
+    if (!(prescale > 0.0f)) return fail(LAFF_E_ARG, "laff_rank_prepare_part: prescale must be positive");
+    if ((Et && !aligned16(Et)) || (Ev && !aligned16(Ev)) || (T && !aligned16(T)) || (V && !aligned16(V)))
+        return fail(LAFF_E_ALIGN, "laff_rank_prepare_part: embeddings and operands must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_rank_prepare(Et, Ev, T, V, Nt, Nv, H, d, precision, prescale, gt_col, col0, s_gt64, band_t, band_v, zero_count,
+                                      pairs, sides, ctx->stream));
+    return LAFF_OK;
+}
+
+int laff_rank_export_pairs(laff_ctx* ctx, const double* s_gt64, int* count, float* S, int lds, int Nv, unsigned* pairs, unsigned pair_cap,
+                           const int* bounds, int world, int col0, unsigned* out, unsigned cap, unsigned* fill) {
+    CHECK_CTX(ctx);
+    if (!s_gt64 || !count || !pairs || !bounds || !out || !fill) return fail(LAFF_E_ARG, "laff_rank_export_pairs: null argument");
+    pair_cap &= ~3u;
+    if (world < 1 || world > 16 || cap < 4 || (cap & 3) || pair_cap < 4) return fail(LAFF_E_SHAPE, "laff_rank_export_pairs: need 1 <= world <= 16, cap %% 4 == 0 (world=%d cap=%u)", world, cap);
+    if (S && lds < Nv) return fail(LAFF_E_SHAPE, "laff_rank_export_pairs: lds=%d < Nv=%d", lds, Nv);
+    if (!aligned16(out)) return fail(LAFF_E_ALIGN, "laff_rank_export_pairs: out must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_rank_export(s_gt64, count, S, lds, pairs, pair_cap, bounds, world, col0, out, cap, fill, ctx->stream));
     return LAFF_OK;
 }
 

@@ -3,6 +3,8 @@
 //   position(t, g) = 1 + #{ c != g : S[t,c] > S[t,g] }.
 // HBM-bound: S is read once, 16 bytes per lane.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "kernels.h"
@@ -245,11 +247,11 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
                                                            int H, int d, float inv_prescale, float unit, float c_acc, const int* __restrict__ gt_col,
                                                            int col0, double* __restrict__ s_gt64, float* __restrict__ band_t,
                                                            float* __restrict__ band_v, int* __restrict__ zero_count,
-                                                           unsigned* __restrict__ pairs) {
+                                                           unsigned* __restrict__ pairs, long vblocks) {
     __shared__ float blkmax[PREP_ROWS];
     const int sl = threadIdx.x & (RG - 1), grp = threadIdx.x / RG;
     const long K = (long)H * d;
-    const long vblocks = ((long)Nv + PREP_VROWS - 1) / PREP_VROWS;       // the (longer) video blocks come first in the grid
+    // vblocks = ceil(Nv / PREP_VROWS) video blocks come first in the grid (they are the longer ones); 0 when only the text side runs
     if (blockIdx.x == 0 && threadIdx.x < 4 && pairs) pairs[threadIdx.x] = 0u;       // pair counter + overflow flag
     const float rsqrt_h = 1.0f / sqrtf((float)H);
     if ((long)blockIdx.x >= vblocks) {
@@ -298,8 +300,11 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
 
 hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
                                int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t,
-                               float* band_v, int* zero_count, unsigned* pairs, hipStream_t st) {
-    const long grid = ((long)Nt + PREP_ROWS - 1) / PREP_ROWS + ((long)Nv + PREP_VROWS - 1) / PREP_VROWS;
+                               float* band_v, int* zero_count, unsigned* pairs, int sides, hipStream_t st) {
+    // sides: 1 = the text rows (s_gt64, band_t, cleared count / list header), 2 = the video rows (band_v), 3 = both
+    const long vblocks = (sides & 2) ? ((long)Nv + PREP_VROWS - 1) / PREP_VROWS : 0;
+    const long grid = ((sides & 1) ? ((long)Nt + PREP_ROWS - 1) / PREP_ROWS : 0) + vblocks;
+    if (grid == 0) return hipSuccess;
     if (grid <= 0 || grid > 0x7fffffffL) return hipErrorInvalidValue;
     const float inv = 1.0f / prescale;
     // fp32 accumulation of the exact products: K terms (3K for a hi/lo split, plus its dropped lo*lo term <= 2^-22), 2^-23 each
@@ -309,7 +314,7 @@ hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, 
     const float c_acc = (float)((double)H * d * (x3 ? 3.0 : 1.0) * 1.1920929e-7 + 9.5367432e-7 + (x3 ? 2.3841858e-7 : 0.0));
 #define LAFF_PREP(P, U)                                                                                                          \
     hipLaunchKernelGGL((rank_prepare_kernel<P>), dim3((unsigned)grid), dim3(256), 0, st, Et, Ev, T, V, Nt, Nv, H, d, inv, U, c_acc, gt_col, \
-                       col0, s_gt64, band_t, band_v, zero_count, pairs)
+                       col0, s_gt64, band_t, band_v, zero_count, pairs, vblocks)
     switch (precision) {
         case LAFF_PREC_FP32: LAFF_PREP(LAFF_PREC_FP32, 5.9604645e-8f); break;
         case LAFF_PREC_FP16: LAFF_PREP(LAFF_PREC_FP16, 4.8828125e-4f); break;
@@ -489,6 +494,145 @@ __global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restri
     }
     (void)lane;
     drain();
+}
+
+// ---- the listed pairs of a VIDEO shard's banded GEMM, exported for the owners of the TEXT rows (laff_amd/dist.py, 'video16': the
+// fp32 text rows never leave their owner, so the exact re-score of a pair happens there).  Reads either list format exactly like the
+// resolve kernel (for the strip kernel's dumps: the band test, the ground-truth entry of S <- the exact score), and appends every pair
+// as {row - bounds[o], col + col0} to the bucket of the owner o of its text row (bounds[o] <= row < bounds[o + 1]): `out` holds `world`
+// buckets of `cap` slots, pre-filled with 0xffffffff -- each bucket, behind a 4-word header {0, 0, cap, 4}, is a list laff_rank_resolve
+// reads (valid pairs first).  One atomic per (wavefront drain, owner).  A full bucket: flag + count[0] poisoned like an overflowing list.
+struct ExportArgs {
+    const int* bounds;     // [world + 1] first text row of every owner
+    int world;
+    int col0;
+    unsigned* out;         // [world][cap][2]
+    unsigned cap;
+    unsigned* fill;        // [world + 1]: pairs appended per bucket, [world] = overflow flag
+};
+constexpr unsigned EXPORT_QCAP = 512;
+__global__ __launch_bounds__(256) void rank_export_kernel(const double* __restrict__ s_gt64, int* __restrict__ count, float* __restrict__ S,
+                                                          long lds, unsigned* __restrict__ pairs, unsigned pair_cap, ExportArgs x) {
+    __shared__ unsigned queue[4][EXPORT_QCAP][3];
+    __shared__ int sbounds[17];
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const int sl = threadIdx.x & (RG - 1);
+    if (threadIdx.x <= (unsigned)x.world) sbounds[threadIdx.x] = x.bounds[threadIdx.x];
+    __syncthreads();
+    auto owner = [&](unsigned row) {
+        int o = 0;
+        for (int k = 1; k < x.world; ++k) o += (int)row >= sbounds[k] ? 1 : 0;
+        return (unsigned)o;
+    };
+    unsigned qn = 0;                                                         // wave-uniform
+    auto poison = [&]() { x.fill[x.world] = 1u; pairs[1] = 1u; count[0] = -(1 << 26); };
+    auto drain = [&]() {
+        for (int o = 0; o < x.world; ++o) {
+            unsigned n_o = 0;
+            for (unsigned i = 0; i < qn; i += 64) {
+                const bool hit = i + lane < qn && queue[wv][i + lane][2] == (unsigned)o;
+                n_o += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+            }
+            if (n_o == 0) continue;
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(x.fill + o, n_o);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + n_o > x.cap && lane == 0) poison();
+            unsigned run = 0;
+            for (unsigned i = 0; i < qn; i += 64) {
+                const bool hit = i + lane < qn && queue[wv][i + lane][2] == (unsigned)o;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (hit) {
+                    const unsigned slot = base + run + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (slot < x.cap) {
+                        unsigned* dst = x.out + ((size_t)o * x.cap + slot) * 2;
+                        dst[0] = queue[wv][i + lane][0] - (unsigned)sbounds[o];
+                        dst[1] = queue[wv][i + lane][1] + (unsigned)x.col0;
+                    }
+                }
+                run += (unsigned)__builtin_popcountll(m);
+            }
+        }
+        qn = 0;
+    };
+    auto push = [&](bool v, unsigned row, unsigned col) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
+        if (v) {
+            const unsigned at = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            queue[wv][at][0] = row;
+            queue[wv][at][1] = col;
+            queue[wv][at][2] = owner(row);
+        }
+        qn += (unsigned)__builtin_popcountll(m);
+    };
+    const unsigned group = (blockIdx.x * 256u + threadIdx.x) / RG, ngroups = gridDim.x * (256u / RG);
+    if (pairs[2] & 0x80000000u) {
+        // the strip kernel's list: dumped groups of 16 raw accumulators (see resolve_groups)
+        const unsigned taken = pairs[0], NW = pairs[2] & 0x7fffffffu, NCH = pairs[3];
+        const unsigned cnt_words = (NCH + 3u) & ~3u;
+        if ((pairs[1] != 0u || NW > NCH || taken > NCH - (NW < NCH ? NW : NCH)) && blockIdx.x == 0 && threadIdx.x == 0) poison();
+        const unsigned long long nchunks = (unsigned long long)NW + taken < NCH ? (unsigned long long)NW + taken : NCH;
+        const unsigned long long slots = nchunks * STRIP_CHUNK;
+        const unsigned* entries = pairs + 4 + cnt_words;
+        const unsigned long long trips = (slots + ngroups - 1) / ngroups;
+        for (unsigned long long it = 0; it < trips; ++it) {
+            if (qn > EXPORT_QCAP - 64) drain();
+            const unsigned long long idx = it * ngroups + group;
+            const bool live = idx < slots && (unsigned)(idx % STRIP_CHUNK) < pairs[4 + (unsigned)(idx / STRIP_CHUNK)];
+            bool inb = false;
+            unsigned row = 0, col = 0;
+            if (live) {
+                const unsigned* e = entries + idx * STRIP_ENTRY_WORDS;
+                const uint4 h0 = *(const uint4*)e;
+                const unsigned mask16 = e[4], gt_col = e[5];
+                const float v = __uint_as_float(e[8 + sl]);
+                const float lo = __uint_as_float(h0.z), hi = __uint_as_float(h0.w);
+                row = h0.x;
+                col = h0.y + 8u * ((unsigned)sl >> 2) + ((unsigned)sl & 3u);
+                if (col == gt_col) {
+                    if (S) S[(long)row * lds + col] = (float)s_gt64[row];
+                } else {
+                    inb = ((mask16 >> sl) & 1u) && __builtin_amdgcn_fmed3f(v, lo, hi) == v;
+                }
+            }
+            push(inb, row, col);
+        }
+    } else {
+        const unsigned n_over = pairs[0], regA = pairs[2];
+        const unsigned long long room = pair_cap > regA ? pair_cap - regA : 0u;
+        if (n_over > room && blockIdx.x == 0 && threadIdx.x == 0) poison();
+        const unsigned n = (unsigned)(n_over < room ? n_over : room);
+        const unsigned long long total = (unsigned long long)regA + n;
+        const unsigned long long nthreads = (unsigned long long)gridDim.x * 256u;
+        const unsigned long long trips = (total + nthreads - 1) / nthreads;
+        for (unsigned long long it = 0; it < trips; ++it) {
+            if (qn > EXPORT_QCAP - 64) drain();
+            const unsigned long long i = it * nthreads + (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+            unsigned row = 0xffffffffu, col = 0;
+            if (i < total) { row = pairs[4 + 2 * i]; col = pairs[4 + 2 * i + 1]; }
+            push(row != 0xffffffffu, row, col);
+        }
+    }
+    drain();
+}
+
+// (a kernel, not hipMemsetAsync: inside a captured HIP graph the two memset nodes of this call did not re-run reliably on replay --
+// the fill counters kept growing: tools/debug/dbg_v16_rccl.py)
+__global__ __launch_bounds__(256) void rank_export_init_kernel(uint4* __restrict__ out, size_t n16, unsigned* __restrict__ fill, int world) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    for (size_t i = i0; i < n16; i += step) out[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    if (i0 <= (size_t)world) fill[i0] = 0u;
+}
+
+hipError_t launch_rank_export(const double* s_gt64, int* count, float* S, int lds, unsigned* pairs, unsigned pair_cap, const int* bounds,
+                              int world, int col0, unsigned* out, unsigned cap, unsigned* fill, hipStream_t st) {
+    if (world < 1 || world > 16 || (cap & 3)) return hipErrorInvalidValue;
+    const size_t n16 = (size_t)world * cap / 2;                   // 16-byte units: cap % 4 == 0, out is 16-byte aligned (api.hip)
+    hipLaunchKernelGGL(rank_export_init_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)(8 * g_num_cus))), dim3(256), 0, st,
+                       (uint4*)out, n16, fill, world);
+    ExportArgs x{bounds, world, col0, out, cap, fill};
+    hipLaunchKernelGGL(rank_export_kernel, dim3((unsigned)(4 * g_num_cus)), dim3(256), 0, st, s_gt64, count, S, (long)lds, pairs, pair_cap, x);
+    return hipGetLastError();
 }
 
 hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64, int* count,

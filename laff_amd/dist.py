@@ -13,8 +13,15 @@ decompositions, both implemented:
       VIDEO embeddings (Nv x K); every text meets its ground-truth video locally, so both all-reduces disappear; the ranks (Nt
       int32) are all-gathered for the replicated metrics.
 
-The fp32 embeddings are what is gathered (not the 16-bit operand) because the exact re-score of the pairs inside the error band
-needs both fp32 rows of a pair on the rank that owns the pair.  choose_sharding() picks the scheme that gathers fewer bytes
+  'video16' (evaluate_sharded_v16): the 'video' decomposition with HALF the gathered bytes on the text side -- what crosses the links is
+      the 16-bit text OPERAND (Nt x K x 2 B) and the fp32 VIDEO embeddings (Nv x K x 4 B, the smaller side); the fp32 text rows never
+      leave their owner.  The owner of a text scores it exactly against its ground-truth video (all fp32 video rows are there) and
+      all-gathers {s_gt64, band_t} (12 B per text); every rank runs the banded GEMM of all texts x its videos; the pairs inside the
+      band (8 B each) go by all-to-all to the owner of their text row, which re-scores them exactly; counts are all-reduced, ranks
+      all-gathered.  No MAX all-reduce.
+
+In 'video' / 'text' the fp32 embeddings are what is gathered (not the 16-bit operand) because the exact re-score of the pairs inside
+the error band needs both fp32 rows of a pair on the rank that owns the pair; 'video16' moves the pair instead of the row.  choose_sharding() picks the scheme that gathers fewer bytes
 (min(Nt, Nv) x K).  S is never gathered.  Uneven shards are padded to the largest shard for the collective and compacted inside
 the next captured phase.
 
@@ -139,6 +146,34 @@ class HipBackend:
     def sim(self, T, V, heads):
         return ops.sim_gemm(T, V, heads=heads)
 
+    # ---- 'video16' (evaluate_sharded_v16) ----
+    def v16_ok(self):
+        return self.precision in ('fp16', 'bf16')           # one-plane 16-bit operand
+
+    def v16_rows(self, T):
+        """the operand as (N, K * 2) bytes: what is all-gathered"""
+        return T.buf[:T.N * T.K * 2].view(T.N, T.K * 2)
+
+    def v16_operand(self, rows2d, N, like):
+        return ops.Packed(rows2d.reshape(-1)[:N * like.K * 2], N, like.K, like.precision, like.prescale)
+
+    def v16_band_video(self, Ev, V):
+        return ops.rank_band_video(Ev, V)
+
+    def v16_prepare_text(self, Et, T, Ev_all, gt_local):
+        return ops.rank_prepare_text(Et, Ev_all, T, gt_local, 0)
+
+    def v16_gemm(self, T_all, V_local, heads, gt, col0, s_gt64, band_t, band_v, want_scores):
+        st = ops.banded_state(T_all, V_local, heads, gt, col0, s_gt64, band_t, band_v)
+        S = ops.sim_gemm_banded(st, want_scores)
+        return S, st
+
+    def v16_export(self, st, S, bounds, col0, cap):
+        return ops.rank_export_pairs(st, S, bounds, col0, cap)
+
+    def v16_resolve(self, Et, Ev_all, s_gt64, count, lst):
+        return ops.rank_resolve_list(Et, Ev_all, s_gt64, count, lst)
+
     def prepare(self, Et, Ev, T, V, gt, col0):
         """Exact ground-truth scores of the texts whose video is in [col0, col0 + Nv), error bands, cleared accumulators."""
         return ops.rank_prepare(Et, Ev, T, V, gt, col0)
@@ -198,6 +233,19 @@ def check_metrics_flag(out_pinned):
     if float(out_pinned[7]) != 0.0:
         raise RuntimeError('laff_amd: the rank metrics kernel flagged an invalid rank (rank < 1): the pair list of the exact-rank '
                            'pipeline overflowed (degenerate scores: raise pair_cap) or the counts are corrupt')
+
+
+def gathered_bytes(scheme, Nt, Nv, K, world, pair_bucket_cap=0):
+    """Payload bytes that reach ONE rank per pass from the others (all-gathers / all-to-all / all-reduce results), by collective."""
+    o = (world - 1) / max(world, 1)
+    if scheme == 'video':
+        return {'all_gather_text_fp32': int(Nt * K * 4 * o), 'all_reduce_s_gt64': Nt * 8, 'all_reduce_count': Nt * 4}
+    if scheme == 'text':
+        return {'all_gather_video_fp32': int(Nv * K * 4 * o), 'all_gather_ranks': int(Nt * 4 * o)}
+    if scheme == 'video16':
+        return {'all_gather_text_16bit': int(Nt * K * 2 * o), 'all_gather_video_fp32': int(Nv * K * 4 * o), 'all_gather_sgt_band': int(Nt * 12 * o),
+                'all_to_all_pairs': int(pair_bucket_cap * 8 * (world - 1)), 'all_reduce_count': Nt * 4, 'all_gather_ranks': int(Nt * 4 * o)}
+    raise ValueError(scheme)
 
 
 def choose_sharding(Nt, Nv):
@@ -433,3 +481,160 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
         mark('metrics')
     return {'S_local': S_local, 'row0': t0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb,
             'rank_state': st}
+
+
+def _all_gather_rows(x2d, nmax, world, comm, group, state, key, async_op=False):
+    """all-gather of equally padded row blocks; returns (gathered (world * nmax, cols) or x2d itself, work or None)"""
+    if not comm:
+        return x2d, None
+    send = _pad_rows(x2d, nmax)
+    shape = (world * nmax, send.shape[1])
+    if key not in state or tuple(state[key].shape) != shape or state[key].dtype != send.dtype:
+        state[key] = torch.empty(shape, dtype=send.dtype, device=send.device)
+    work = dist.all_gather_into_tensor(state[key], send, group=group, async_op=async_op)
+    return state[key], (work if async_op else None)
+
+
+def _compact2d(gathered, sizes, nmax):
+    if all(hi - lo == nmax for lo, hi in sizes):
+        return gathered
+    return torch.cat([gathered[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
+
+
+def evaluate_sharded_v16(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True, timer=None,
+                         want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False, finish_tag='',
+                         pair_bucket_cap=None):
+    """The 'video16' scheme of the module docstring: rank g owns videos [v0, v1) and the column block S[:, v0:v1] as in
+    evaluate_sharded, but the text side crosses the links as the 16-bit operand; exact re-scores happen at the text owners.
+    pair_bucket_cap: slots of one (sender, owner) bucket of the pair all-to-all (default: the even share of 32 pairs per text -- C4 lists
+    2.4 per text --, at least 4096).
+    Returns dict(S_local (Nt, v1 - v0), col0, ranks (Nt,), metrics, gathered_bytes)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    comm = world > 1 or (force_collectives and dist.is_initialized())
+    mark = timer.mark if timer is not None else (lambda name: None)
+    run = runner if runner is not None else _eager
+    state = state if state is not None else {}
+    if runner is not None and metrics_out is None and want_metrics:
+        raise ValueError('a GraphRunner needs metrics_out (pinned buffer): the synchronising metrics call cannot be captured')
+    v0, v1 = shard_bounds(Nv, world, rank)
+    t0, t1 = shard_bounds(Nt, world, rank)
+    tsizes = [shard_bounds(Nt, world, r) for r in range(world)]
+    vsizes = [shard_bounds(Nv, world, r) for r in range(world)]
+    tmax = max(hi - lo for lo, hi in tsizes)
+    vmax = max(hi - lo for lo, hi in vsizes)
+    if pair_bucket_cap is None:
+        pair_bucket_cap = max(4096, (32 * Nt // max(world * world, 1) + 3) & ~3)
+    cap = (int(pair_bucket_cap) + 3) & ~3
+    if hasattr(compute, 'set_unpacked'):
+        compute.set_unpacked(None)
+    with torch.no_grad():
+        dev = gt.device
+        if 'bounds' not in state or state['bounds'].numel() != world + 1 or state['bounds'].device != dev:
+            state['bounds'] = torch.tensor([lo for lo, _ in tsizes] + [Nt], dtype=torch.int32, device=dev)
+        if 'gt_local' not in state or state['gt_local'].numel() != t1 - t0 or state['gt_local'].device != dev:
+            state['gt_local'] = torch.empty(t1 - t0, dtype=gt.dtype, device=dev)
+        state['gt_local'].copy_(gt[t0:t1])
+        gt_local = state['gt_local']
+
+        # ---- towers; the text operand and the video rows start travelling while the other tower runs ----
+        def text_phase():
+            txt_emb = compute.embed_text(txt_feats_local)
+            T = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
+            return txt_emb, T, compute.v16_rows(T)
+        txt_emb, T_local, t_rows = run('text16', text_phase)
+        mark('txt_tower')
+        t_all, w1 = _all_gather_rows(t_rows, tmax, world, comm, group, state, 'g_t16', async_op=True)
+
+        def video_phase():
+            vis_emb = compute.embed_video(vis_feats_local)
+            V = compute.pack(vis_emb, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack(vis_emb)
+            return vis_emb, V, compute.v16_band_video(vis_emb, V), _flat_rows(vis_emb)
+        vis_emb, V_local, band_v, v_rows = run('video16', video_phase)
+        mark('vis_tower')
+        v_all, w2 = _all_gather_rows(v_rows, vmax, world, comm, group, state, 'g_v32', async_op=True)
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()
+        mark('all_gather_wait')
+
+        # ---- the text owner: exact ground-truth scores + bands of its rows -> everybody ----
+        def owner_phase():
+            Ev_all = _compact(v_all, vsizes, vmax, heads) if comm else vis_emb
+            s_gt64, band_t = compute.v16_prepare_text(txt_emb, T_local, Ev_all, gt_local)
+            pay = torch.empty((t1 - t0, 3), dtype=torch.float32, device=s_gt64.device)
+            pay[:, :2] = s_gt64.view(torch.float32).view(-1, 2)
+            pay[:, 2] = band_t[:t1 - t0]
+            return Ev_all, s_gt64, band_t, pay
+        Ev_all, s_gt64_l, band_t_l, pay = run('owner16', owner_phase)
+        mark('prep')
+        pay_all, _ = _all_gather_rows(pay, tmax, world, comm, group, state, 'g_pay')
+        mark('allgather_sgt_band')
+
+        # ---- the video owner: banded GEMM of ALL texts x its videos; pairs inside the band -> buckets per text owner ----
+        def gemm_phase():
+            if comm:
+                rows = _compact2d(t_all, tsizes, tmax)
+                T_all = compute.v16_operand(rows, Nt, T_local)
+                p = _compact2d(pay_all, tsizes, tmax)
+                s_all = p[:, :2].contiguous().view(torch.float64).view(-1)
+                b_all = torch.zeros(Nt + 4, dtype=torch.float32, device=p.device)
+                b_all[:Nt] = p[:, 2]
+            else:
+                T_all, s_all, b_all = T_local, s_gt64_l, band_t_l
+            return compute.v16_gemm(T_all, V_local, heads, gt, v0, s_all, b_all, band_v, want_scores)
+        S_local, st = run('gemm16', gemm_phase)
+        mark('sim_gemm')
+        send, fill = run('export16', lambda: compute.v16_export(st, S_local, state['bounds'], v0, cap))
+        mark('export_pairs')
+        count = st.count
+        if comm:
+            if 'recv' not in state or state['recv'].numel() != 4 + 2 * world * cap:
+                state['recv'] = torch.empty(4 + 2 * world * cap, dtype=torch.int32, device=send.device)
+                state['recv'][:4] = torch.tensor([0, 0, world * cap, 4], dtype=torch.int32, device=send.device)
+            lst = state['recv']
+            dist.all_to_all_single(lst[4:].view(world, cap, 2), send, group=group)
+            dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)          # (a full bucket poisons count[0]: stays negative)
+            mark('alltoall_pairs')
+        else:
+            lst = torch.empty(4 + 2 * cap, dtype=torch.int32, device=send.device)
+            lst[:4] = torch.tensor([0, 0, cap, 4], dtype=torch.int32, device=send.device)
+            lst[4:] = send.reshape(-1)
+
+        # ---- the text owner: exact re-score of the pairs of its rows; ranks -> everybody ----
+        def resolve_phase():
+            mine = count[t0:t1].clone()
+            compute.v16_resolve(txt_emb, Ev_all, s_gt64_l, mine, lst)
+            r = (mine + 1).to(torch.int32)
+            if comm and r.numel() != tmax:
+                pad = torch.ones(tmax, dtype=torch.int32, device=r.device)
+                pad[:r.numel()] = r
+                r = pad
+            return r.contiguous()
+        mine = run('resolve16', resolve_phase)
+        if comm:
+            if 'g_ranks' not in state or state['g_ranks'].numel() != world * tmax:
+                state['g_ranks'] = torch.empty(world * tmax, dtype=torch.int32, device=mine.device)
+            all_ranks = state['g_ranks']
+            dist.all_gather_into_tensor(all_ranks, mine, group=group)
+            mark('allgather_ranks')
+        else:
+            all_ranks = mine
+
+        def finish():
+            if comm and not all(hi - lo == tmax for lo, hi in tsizes):
+                ranks = torch.cat([all_ranks[r * tmax: r * tmax + (hi - lo)] for r, (lo, hi) in enumerate(tsizes)])
+            else:
+                ranks = all_ranks[:Nt]
+            if metrics_out is not None:
+                compute.metrics_async(ranks, metrics_out)
+            return ranks
+        ranks = run('finish16' + finish_tag, finish)
+        mark('rank')
+        metrics = None
+        if metrics_out is None and want_metrics:
+            metrics = compute.metrics(ranks)
+        mark('metrics')
+    K = txt_emb.reshape(txt_emb.shape[0], -1).shape[1]
+    return {'S_local': S_local, 'col0': v0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb, 'rank_state': st,
+            'pair_fill': fill, 'gathered_bytes': gathered_bytes('video16', Nt, Nv, K, world, cap)}

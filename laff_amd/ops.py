@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, FcSplitProblem, FcStripProblem, Plane, check, FcFusedProblem, RankSide)
 
-__all__ = ['rank_prepare', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'topk_from_operands', 'alloc_scores', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'fc_strip_pack', 'fc_strip_eligible', 'fc_act_bn_strip_grouped', 'StripWeights', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts', 'FusedPrepare', 'fused_prepare_eligible',
+__all__ = ['rank_prepare', 'rank_prepare_text', 'rank_band_video', 'rank_export_pairs', 'rank_resolve_list', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'topk_from_operands', 'alloc_scores', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'fc_strip_pack', 'fc_strip_eligible', 'fc_act_bn_strip_grouped', 'StripWeights', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts', 'FusedPrepare', 'fused_prepare_eligible',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -756,6 +756,80 @@ def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None):
     _call('rank_prepare', lib.laff_rank_prepare, h, _ptr(Et), _ptr(Ev), _ptr(T.buf), _ptr(V.buf), Nt, Nv, H, d, PREC[T.precision],
           float(T.prescale), _ptr(gt_col), int(col0), _ptr(s_gt64), _ptr(band_t), _ptr(band_v), _ptr(count), _ptr(pairs))
     return RankState(Et, Ev, T, V, H, gt_col, int(col0), s_gt64, band_t, band_v, count, pairs, cap)
+
+
+def rank_prepare_text(Et, Ev, T, gt_col, col0=0, prescale=None):
+    """The TEXT side of laff_rank_prepare alone (laff_rank_prepare_part, sides = 1): exact ground-truth scores of the texts Et against
+    the fp32 video rows Ev (gt_col - col0 indexes them; -inf outside) and their error bands.  Returns (s_gt64, band_t)."""
+    Et, Ev = _emb3(Et, 'Et'), _emb3(Ev, 'Ev')
+    Nt, H, d = Et.shape
+    if tuple(Ev.shape[1:]) != (H, d) or T.N != Nt or T.K != H * d:
+        raise ValueError('embeddings %s / %s do not match the operand (%d x %d)' % (tuple(Et.shape), tuple(Ev.shape), T.N, T.K))
+    _dev(gt_col, 'gt_col', torch.int32)
+    if gt_col.numel() != Nt or not gt_col.is_contiguous():
+        raise ValueError('gt_col must be a contiguous int32 vector of %d' % Nt)
+    dev = Et.device
+    s_gt64 = torch.empty((Nt + 2,), device=dev, dtype=torch.float64)[:Nt]
+    band_t = torch.empty((Nt + 4,), device=dev, dtype=torch.float32)
+    lib, h = _context(dev)
+    _call('rank_prepare', lib.laff_rank_prepare_part, h, 1, _ptr(Et), _ptr(Ev), _ptr(T.buf), None, Nt, Ev.shape[0], H, d, PREC[T.precision],
+          float(T.prescale), _ptr(gt_col), int(col0), _ptr(s_gt64), _ptr(band_t), None, None, None)
+    return s_gt64, band_t
+
+
+def rank_band_video(Ev, V):
+    """The VIDEO side of laff_rank_prepare alone (sides = 2): band_v of the rows Ev / their operand V, in the layout the banded GEMM
+    reads (per column, then per 64-column block)."""
+    Ev = _emb3(Ev, 'Ev')
+    Nv, H, d = Ev.shape
+    if V.N != Nv or V.K != H * d:
+        raise ValueError('embeddings %s do not match the operand (%d x %d)' % (tuple(Ev.shape), V.N, V.K))
+    band_v = torch.empty((((Nv + 3) & ~3) + (Nv + 63) // 64 + 4,), device=Ev.device, dtype=torch.float32)
+    lib, h = _context(Ev.device)
+    _call('rank_prepare', lib.laff_rank_prepare_part, h, 2, None, _ptr(Ev), None, _ptr(V.buf), 0, Nv, H, d, PREC[V.precision], float(V.prescale),
+          None, 0, None, None, _ptr(band_v), None, None)
+    return band_v
+
+
+def banded_state(T, V, heads, gt_col, col0, s_gt64, band_t, band_v, pair_cap=None):
+    """A RankState for laff_sim_gemm_banded assembled from parts (no fp32 rows: its list is exported, not resolved here)."""
+    _dev(gt_col, 'gt_col', torch.int32)
+    if gt_col.data_ptr() % 16:
+        gt_col = gt_col.clone()
+    dev = T.buf.device
+    cap = (int(pair_cap) if pair_cap is not None else default_pair_cap(T.N)) & ~3
+    count = torch.zeros((T.N,), device=dev, dtype=torch.int32)
+    pairs = torch.empty((4 + 2 * cap,), device=dev, dtype=torch.int32)
+    pairs[:4].zero_()
+    return RankState(None, None, T, V, heads, gt_col, int(col0), s_gt64, band_t, band_v, count, pairs, cap)
+
+
+def rank_export_pairs(st, S, bounds, col0, cap):
+    """The listed pairs of a banded GEMM, bucketed by the owner of the text row (laff_rank_export_pairs).  bounds: int32 device
+    tensor (world + 1).  Returns (out (world, cap, 2) int32 -- unused slots -1 --, fill (world + 1) int32)."""
+    world = bounds.numel() - 1
+    cap = (int(cap) + 3) & ~3
+    dev = st.pairs.device
+    out = torch.empty((world, cap, 2), device=dev, dtype=torch.int32)
+    fill = torch.empty((world + 1,), device=dev, dtype=torch.int32)
+    lds = 0
+    if S is not None:
+        S, lds = _rows(S, 'S')
+    lib, h = _context(dev)
+    _call('rank_export', lib.laff_rank_export_pairs, h, _ptr(st.s_gt64), _ptr(st.count), _ptr(S), lds, st.V.N, _ptr(st.pairs), st.pair_cap,
+          _ptr(bounds), world, int(col0), _ptr(out), cap, _ptr(fill))
+    return out, fill
+
+
+def rank_resolve_list(Et, Ev, s_gt64, count, lst):
+    """laff_rank_resolve on a plain list: lst int32 (4 + 2 n), header {0, 0, n, 4} then n slots {row, col} with unused slots -1 and
+    the valid pairs first in every group of four (what concatenated laff_rank_export_pairs buckets are).  count += wins."""
+    Et, Ev = _emb3(Et, 'Et'), _emb3(Ev, 'Ev')
+    Nt, H, d = Et.shape
+    n = (lst.numel() - 4) // 2
+    lib, h = _context(Et.device)
+    _call('rank_resolve', lib.laff_rank_resolve, h, _ptr(Et), _ptr(Ev), Nt, Ev.shape[0], H, d, _ptr(s_gt64), _ptr(count), None, 0, _ptr(lst), n)
+    return count
 
 
 def sim_gemm_banded(st, want_scores=True, out=None):

@@ -27,6 +27,9 @@ def test_self_launch_two_ranks_dryrun():
     assert line['steps'] == 2 and line['warmup'] == 1 and line['scaling'] == 'strong'
     assert line['config']['shard'] == 'video'              # the decomposition BASELINE.json names is the headline
     assert line['alt_shard']['shard'] == 'text' and line['alt_shard']['ranks_equal']
+    assert [a['shard'] for a in line['alt_shards']] == ['text', 'video16'] and all(a['ranks_equal'] for a in line['alt_shards'])
+    b16, b32 = line['alt_shards'][1]['gathered_bytes_per_step'], line['gathered_bytes_per_step']
+    assert b16['all_gather_text_16bit'] * 2 == b32['all_gather_text_fp32'] and b16['all_to_all_pairs'] > 0
     assert line['value'] > 0 and line['ms_per_step'] > 0
 
 

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from laff_amd.dist import evaluate_sharded, evaluate_sharded_by_text, shard_bounds
+from laff_amd.dist import evaluate_sharded, evaluate_sharded_by_text, evaluate_sharded_v16, gathered_bytes, shard_bounds
 from oracle import laff_oracle as O
 
 
@@ -101,3 +101,55 @@ def test_text_row_sharding_equals_single(world, tmp_path):
         np.testing.assert_allclose(z['metrics'], np.array(single['metrics']), rtol=0, atol=1e-12)
         rows.append(z['S'])
     np.testing.assert_allclose(np.concatenate(rows, axis=0), single['S_local'].numpy(), rtol=0, atol=1e-6)
+
+
+def _worker_v16(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        xt, xv, gt, Wt, Wv = _problem()
+        t0, t1 = shard_bounds(len(xt), world, rank)
+        v0, v1 = shard_bounds(len(xv), world, rank)
+        res = evaluate_sharded_v16(OracleBackend(Wt, Wv), {'x': torch.from_numpy(xv[v0:v1])}, {'x': torch.from_numpy(xt[t0:t1])},
+                                   torch.from_numpy(gt), len(xt), len(xv), 1, pair_bucket_cap=64)
+        np.savez(os.path.join(out_dir, 'h%d.npz' % rank), ranks=res['ranks'].numpy(), metrics=np.array(res['metrics']),
+                 S=res['S_local'].numpy(), col0=res['col0'], fill=res['pair_fill'].numpy(),
+                 bytes=np.array(sorted(res['gathered_bytes'].items()), dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_video16_equals_single(world, tmp_path):
+    """'video16': the 16-bit text operand + the fp32 video rows are gathered, the in-band pairs travel to the owner of their text
+    row (all-to-all of 8-byte pairs) and are re-scored there -- ranks equal to the single-process ones, uneven shards (61 / 23 rows),
+    and pairs really did travel."""
+    xt, xv, gt, Wt, Wv = _problem()
+    single = evaluate_sharded(OracleBackend(Wt, Wv), {'x': torch.from_numpy(xv)}, {'x': torch.from_numpy(xt)},
+                              torch.from_numpy(gt), len(xt), len(xv), 1)
+    alone = evaluate_sharded_v16(OracleBackend(Wt, Wv), {'x': torch.from_numpy(xv)}, {'x': torch.from_numpy(xt)},
+                                 torch.from_numpy(gt), len(xt), len(xv), 1, pair_bucket_cap=4096)
+    assert np.array_equal(alone['ranks'].numpy(), single['ranks'].numpy())
+    assert int(alone['pair_fill'][0]) > 0                                   # the band is not empty: the resolve path is exercised
+    mp.spawn(_worker_v16, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    cols, moved = [], 0
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), 'h%d.npz' % r), allow_pickle=True)
+        assert np.array_equal(z['ranks'], single['ranks'].numpy())
+        np.testing.assert_allclose(z['metrics'], np.array(single['metrics']), rtol=0, atol=1e-12)
+        cols.append(z['S'])
+        assert z['fill'][world] == 0                                        # no bucket overflowed
+        moved += int(z['fill'][:world].sum()) - int(z['fill'][r])          # pairs whose text row lives on another rank
+    assert moved > 0
+    np.testing.assert_allclose(np.concatenate(cols, axis=1), single['S_local'].numpy(), rtol=0, atol=1e-6)
+    b = gathered_bytes('video16', 40000, 10000, 512, 8, 10240)
+    assert b['all_gather_text_16bit'] * 2 == gathered_bytes('video', 40000, 10000, 512, 8)['all_gather_text_fp32']
+
+
+def test_video16_full_bucket_poisons_the_ranks():
+    """a pair bucket too small for the band: flagged, and rank 0 of the result is < 1 (what the metrics kernel turns into an error)"""
+    xt, xv, gt, Wt, Wv = _problem()
+    res = evaluate_sharded_v16(OracleBackend(Wt, Wv), {'x': torch.from_numpy(xv)}, {'x': torch.from_numpy(xt)},
+                               torch.from_numpy(gt), len(xt), len(xv), 1, pair_bucket_cap=4, want_metrics=False)
+    assert int(res['pair_fill'][1]) == 1 and int(res['ranks'][0]) < 1
