@@ -185,13 +185,34 @@ def _free_port():
     return port
 
 
+def visible_gpus():
+    """GPU agents of this node, counted from the KFD topology in sysfs (a node with SIMDs is a GPU), cut down by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES; torch.cuda.device_count() -- which on some ROCm builds reaches hipGetDeviceCount, i.e. initialises the
+    runtime in this parent process -- only when sysfs has no topology."""
+    n = 0
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get('simd_count', '0')) > 0:
+                n += 1
+    except OSError:
+        return torch.cuda.device_count()
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
+
+
 def self_launch(n, argv):
     """Parent of a `--gpus N` run without a launcher: N ranks under torch.distributed.run as a child process (never an exec: this
     image refuses to replace a process image once anything may have initialised the GPU), rank 0's line relayed."""
     import subprocess
     dry = os.environ.get('LAFF_BENCH_DRYRUN') == '1'
     if not dry:
-        have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        have = visible_gpus()                     # (from sysfs: the parent stays clear of the HIP runtime altogether)
         if have < n:
             print('bench.py: --gpus %d but this node has %d visible GPU(s)' % (n, have), file=sys.stderr)
             return 2
@@ -718,6 +739,14 @@ def main():
                                         'precision %s / %s, one GPU' % (sha, args.workload, args.precision, args.fc_precision))
         except Exception as e:  # noqa: BLE001
             roof['traffic_note'] = 'traffic lookup failed: %s' % e
+        # the denominators are the NOMINAL peaks of MI355X_MICROARCH.md; what the chip sustains under this step is lower
+        roof['peak_note'] = ('nominal peaks: 8 TB/s HBM3E (6.29 TB/s measured copy rate), 2.5 PFLOP/s dense fp16 at 2.4 GHz.  The step runs '
+                             'at the 1,400 W package cap: held shader clock %s MHz (sustained.sclk_mhz_samples), i.e. an MFMA ceiling of '
+                             '~%.1f PFLOP/s at the clock actually held'
+                             % (('%d-%d' % (min(sustained['sclk_mhz_samples']), max(sustained['sclk_mhz_samples'])))
+                                if sustained and sustained.get('sclk_mhz_samples') else 'unsampled',
+                                2.5 * (sum(sustained['sclk_mhz_samples']) / len(sustained['sclk_mhz_samples']) / 2400.0)
+                                if sustained and sustained.get('sclk_mhz_samples') else 2.5))
         m = res['metrics']
         agreement = None
         if world == 1 and not args.no_cpu_baseline:

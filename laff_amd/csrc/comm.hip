@@ -4,11 +4,26 @@
 // runs two RCCL instances by accident.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>) && !defined(LAFF_NO_RCCL_HEADER)
 #include <rccl/rccl.h>
+#else
+// A ROCm install without the RCCL headers: the library is looked up at run time anyway, so the handful of types and enumerators of
+// NCCL's stable C ABI that this file uses are declared here (values as in nccl.h / rccl.h).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7,
+               ncclFloat64 = 8, ncclBfloat16 = 9 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+}
+#endif
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/laff_hip.h"
@@ -45,8 +60,7 @@ int failf(int code, const char* fmt, ...) {
     return code;
 }
 
-int load_rccl() {
-    if (g_rccl.handle) return LAFF_OK;
+int load_rccl_once() {
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names)
@@ -67,6 +81,14 @@ int load_rccl() {
 #undef LAFF_SYM
     g_rccl = r;
     return LAFF_OK;
+}
+
+// first callers may race: one of them loads, the others wait; a failed load is retried by the next call (its message is thread-local)
+int load_rccl() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (g_rccl.handle) return LAFF_OK;
+    return load_rccl_once();
 }
 
 #define RCCL_TRY(expr)                                                                                         \

@@ -198,7 +198,7 @@ __device__ __forceinline__ void rank_side(const FuseArgs& a, long n, int h, int 
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
         if (j * 256 + lane * 4 < d) *(float4*)(&erow[wave][j * 256 + lane * 4]) = g[j];
-    if (wave == 0 && lane < 4) item_n[lane] = -1;                   // (waves of a last, partial block that have no item have exited)
+    if (wave == 0 && lane < 4) item_n[lane] = -1;                   // (waves of a last, partial block that have no item: rank_side_idle)
     __syncthreads();
     if (lane == 0) { item_n[wave] = n; item_h[wave] = h; }
     __syncthreads();
@@ -289,6 +289,15 @@ __device__ __forceinline__ void rank_side(const FuseArgs& a, long n, int h, int 
     }
 }
 
+// a wavefront of a last, partial block that has no item: with rp_side set the block's other waves meet at rank_side's two barriers --
+// it meets them there too instead of leaving (a barrier that counts on terminated waves being dropped is undefined in HIP)
+__device__ __forceinline__ void rank_side_idle(const FuseArgs& a) {
+    if (a.rp_side) {
+        __syncthreads();
+        __syncthreads();
+    }
+}
+
 // ---- register-resident variant: d <= 256*NCH ----------------------------------------------------------------
 template <int L, int NCH>
 __global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
@@ -298,10 +307,10 @@ __global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
     if (a.head_major) {                                          // gather planes: all four waves of a block share the head
         h = (int)(blockIdx.x % (unsigned)a.H);
         n = (long)(blockIdx.x / (unsigned)a.H) * 4 + (threadIdx.x >> 6);
-        if (n >= a.N) return;
+        if (n >= a.N) { rank_side_idle(a); return; }
     } else {
         const long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (it >= (long)a.N * a.H) return;
+        if (it >= (long)a.N * a.H) { rank_side_idle(a); return; }
         n = it / a.H;
         h = (int)(it - n * a.H);
     }
@@ -481,6 +490,8 @@ static hipError_t launch_fuse_L(const FuseArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((fuse_reg_kernel<L, 1>), dim3(grid), dim3(256), 0, st, a);
     else if (a.d <= 512)
         hipLaunchKernelGGL((fuse_reg_kernel<L, 2>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.rp_side)
+        return hipErrorInvalidValue;           // laff_rank_prepare's work rides in the register-resident kernel only (d <= 512)
     else
         hipLaunchKernelGGL((fuse_stream_kernel<L>), dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();

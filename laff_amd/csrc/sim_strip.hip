@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
     // per entry, as a first version had it behind small fixed segments, it cost a third of the launch).
     const unsigned NW = (unsigned)nranges * 4u;
     const unsigned total_words = 2u * pin_s(a.pair_cap);
-    const unsigned NCH = pin_s(total_words / (1u + STRIP_CHUNK * STRIP_ENTRY_WORDS));
+    // chunks that fit behind the header and the count table (rounded up to 4 words): NCH + 3 + NCH * chunk words <= total_words
+    const unsigned NCH = pin_s(total_words >= 3u ? (total_words - 3u) / (1u + STRIP_CHUNK * STRIP_ENTRY_WORDS) : 0u);
     const unsigned cnt_words = (NCH + 3u) & ~3u;
     const unsigned wave_global = (unsigned)blockIdx.x * 4u + (unsigned)wave;
     unsigned cur_chunk = wave_global, cur_n = 0;                            // wave-uniform: the chunk being filled, entries in it

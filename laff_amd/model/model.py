@@ -527,17 +527,21 @@ class VisMutiTransformNetPlusFrameFeat(nn.Module):
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
-        space_dict = opt.vis_fc_layers[0]
+        # One TransformNet per input feature under the feature's own name (the state_dict keys of the reference: model/model.py:
+        # 2101-2128): video-level features and, with frame_feat_input, the per-frame ones (pooled over frames first, frame_vector).
+        # A feature listed in vis_no_transform keeps its width: BatchNorm only, no FC, no activation.
+        dims = opt.vis_fc_layers[0]
+        names = list(dims.keys())
         if opt.frame_feat_input:
-            for frame_name in opt.vid_frame_feats:
-                space_dict[frame_name] = opt.vis_fc_layers[0][frame_name]
-        self.vis_net_space_dict = space_dict
-        for each in space_dict.keys():
-            if each not in opt.vis_no_transform:
-                self.add_module(each, TransformNet((space_dict[each], opt.vis_fc_layers[1]), opt))
+            names += [f for f in opt.vid_frame_feats if f not in dims]
+        D_out = opt.vis_fc_layers[1]
+        self.vis_net_space_dict = space_dict = {f: opt.vis_fc_layers[0][f] for f in names}
+        for f, width in space_dict.items():
+            if f in opt.vis_no_transform:
+                net = TransformNet((width, D_out), None, dropout=None, batch_norm=True, activation=False, fc=False)
             else:
-                self.add_module(each, TransformNet((space_dict[each], opt.vis_fc_layers[1]), None, dropout=None,
-                                                   batch_norm=True, activation=False, fc=False))
+                net = TransformNet((width, D_out), opt)
+            self.add_module(f, net)
         D = opt.vis_fc_layers[1]
         self.vis_attention_layer = get_attention_layer(opt.vis_attention, D, len(space_dict), opt)
         self.frame_attention = nn.ModuleDict()
@@ -690,6 +694,9 @@ class W2VVPP(nn.Module):
     predict_precision = 'fp16x3'
     #: retrieve() / predict() run each tower ONCE over all loader batches (False: one launch set per batch, like the reference's loop)
     coalesce_loader_batches = True
+    #: ... for collections of at most this many videos / captions: the batches of a loader are concatenated in host memory first (the
+    #: reference bounds host memory the same way: predict_batch above 5e4 videos, model/model.py:1081-1128)
+    coalesce_max_items = 400000
 
     def _embed_whole(self, vis_loader, txt_loader):
         """Both towers once over the whole matrices: every FC projection of both towers in ONE grouped launch, one fuse launch per
@@ -701,14 +708,18 @@ class W2VVPP(nn.Module):
         if hasattr(vis_loader, 'whole') and hasattr(txt_loader, 'whole'):
             out, (cap, _, txt_ids) = vis_loader.whole(), txt_loader.whole()
         else:
+            # the loaders are walked ONCE: what was collected is handed back to the per-batch route when it cannot be concatenated
+            # (errors raised by the loaders themselves propagate)
+            vb, tb = list(vis_loader), list(txt_loader)
+            self._collected_batches = (vb, tb)
             try:
-                out = coalesce_batches(list(vis_loader))
-                tb = list(txt_loader)
+                out = coalesce_batches(vb)
                 cap, txt_ids = coalesce_batches([b[0] for b in tb]), [i for b in tb for i in b[2]]
             except (TypeError, ValueError, RuntimeError):
                 return None
             if out is None or cap is None:
                 return None
+            self._collected_batches = None
         pending = []
         fin_v = self.vis_net.prepare(out['vis_feat_dict'], out.get('vis_frame_feat_dict', {}), pending)
         fin_t = self.txt_net.prepare(cap, pending)
@@ -732,9 +743,14 @@ class W2VVPP(nn.Module):
         precision = precision or self.sim_precision or self.predict_precision
         with torch.no_grad():
             whole = None
+            self._collected_batches = None
+            vis_loader_given = vis_loader
             if (self.coalesce_loader_batches and (not record_emb or self.video_all_embs is None) and
-                    _loader_len(vis_loader) > 0 and _loader_len(txt_loader) > 0):
+                    0 < _loader_len(vis_loader) <= self.coalesce_max_items and 0 < _loader_len(txt_loader) <= self.coalesce_max_items):
                 whole = self._embed_whole(vis_loader, txt_loader)
+            if whole is None and self._collected_batches is not None:
+                vis_loader, txt_loader = self._collected_batches       # walk what was collected, not the loaders a second time
+                self._collected_batches = None
             if whole is not None:
                 self.video_all_embs, self.video_idxs_list, self.vis_ids, txt_all, txt_ids = whole
             else:
@@ -773,7 +789,7 @@ class W2VVPP(nn.Module):
                     T = ops.pack_rows(to_device_and_float16(Et), True, 1e-13, prec)
                     V = ops.pack_rows(to_device_and_float16(Ev), True, 1e-13, prec)
                     S, count, st = ops.exact_ranks(Et, Ev, T, V, gt, pair_cap=cap)
-                    if not st.listed_pairs()[1]:
+                    if not st.overflowed():
                         break
                     del S, count, st
                 else:
@@ -785,7 +801,7 @@ class W2VVPP(nn.Module):
             else:
                 S = self.get_txt2vis_matrix(txt_all, vis_used, measure, precision)
             if not identity:
-                full = torch.zeros((S.shape[0], len(vis_loader.dataset)), device=S.device, dtype=S.dtype)
+                full = torch.zeros((S.shape[0], len(vis_loader_given.dataset)), device=S.device, dtype=S.dtype)
                 full[:, torch.as_tensor(cols, device=S.device)] = S
                 S = full
         return S, txt_ids, self.vis_ids

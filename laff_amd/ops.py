@@ -616,7 +616,11 @@ class RankState:
           strip kernel: header {chunks taken, overflow flag, NW | 1 << 31, NCH}, NCH per-chunk entry counts, then NCH chunks of 64
                         entries {row, colbase, lo, hi | mask16, the row's ground-truth column, 0, 0 | 16 raw accumulators}: the
                         pairs are the listed elements with lo <= x <= hi (the test laff_rank_resolve applies)."""
-        return int(self.pair_indices().shape[0]), bool(self._header()[1])
+        return int(self.pair_indices().shape[0]), self.overflowed()
+
+    def overflowed(self):
+        """The list's overflow flag (one 16-byte copy; synchronises): pairs were dropped, the counts are poisoned."""
+        return bool(self._header()[1])
 
     def pair_indices(self):
         """(n, 2) int64 tensor of the (row, col) pairs inside the band -- synchronises; diagnostics / tests only."""

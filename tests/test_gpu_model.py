@@ -359,3 +359,53 @@ def test_oversized_fc_problem_is_cut_into_row_chunks():
         M.FC_PRECISION = 'fp32'
         M._row_chunks = old
     assert got[0] is out and torch.equal(out, ref) and torch.equal(got[1], ref[:100])
+
+
+def test_retrieve_walks_the_overflow_ladder(monkeypatch):
+    """model.retrieve() on degenerate scores (hundreds of near-duplicate videos inside every query's error band) with a pair list far
+    too small: the default-size pass overflows, the 8x pass overflows, the pass on hi/lo split operands (band ~1e-6) fits -- nothing
+    of an overflowed pass is published, and the ranks are those of the float64 scores (model/model.py:1018-1079 is the call this
+    replaces; the ranking loop is predictor.py:232-244)."""
+    from laff_amd import ops, predictor
+    g = np.random.default_rng(7)
+    cfg = make_config({'a': 64, 'b': 48}, {'bow': 40, 'w2v': 24}, 512, 1, 'LAFF', [], [])
+    torch.manual_seed(11)
+    model = get_model('LAFF', DEV, cfg).eval()
+    Nv, per = 600, 3
+    base_a, base_b = g.normal(0, 1, (1, 64)).astype(np.float32), g.normal(0, 1, (1, 48)).astype(np.float32)
+    vis = {'a': base_a + 0.05 * g.normal(0, 1, (Nv, 64)).astype(np.float32),              # 600 videos clustered around one point
+           'b': base_b + 0.05 * g.normal(0, 1, (Nv, 48)).astype(np.float32)}
+    vis_ids = ['video%d' % i for i in range(Nv)]
+    txt_ids = ['video%d#%d' % (i, k) for i in range(Nv) for k in range(per)]
+    Nt = len(txt_ids)
+    txt = {'bow_encoding': g.normal(0, 1, (Nt, 40)).astype(np.float32), 'w2v_encoding': g.normal(0, 1, (Nt, 24)).astype(np.float32)}
+    vl = VisLoader(vis, vis_ids, 64)
+    tl = TxtLoader(txt, txt_ids, 64, np.arange(Nt))
+    calls = []
+    real = ops.exact_ranks
+
+    def spy(Et, Ev, T, V, gt, want_scores=True, col0=0, pair_cap=None):
+        out = real(Et, Ev, T, V, gt, want_scores, col0, pair_cap)
+        calls.append((T.precision, pair_cap, out[2].overflowed()))
+        return out
+    monkeypatch.setattr(ops, 'exact_ranks', spy)
+    # retrieve() asks for the list sizes of the second and third attempt (8 x default) before the first attempt takes the default
+    # itself: 8 slots, then 64, then 2^21 for the split operands
+    sizes = iter([8, 1 << 18, 8])
+    monkeypatch.setattr(ops, 'default_pair_cap', lambda n: next(sizes))
+    S, out_txt, out_vis = model.retrieve(tl, vl, precision='fp16')
+    assert [c[0] for c in calls] == ['fp16', 'fp16', 'fp16x3'] and [c[2] for c in calls] == [True, True, False]
+    assert calls[0][1] is None and calls[1][1] == 64 and calls[2][1] == 1 << 21
+    gt = predictor.gt_columns(out_txt, out_vis)
+    te = torch.cat([model.txt_net(c) for c, _, _ in tl]).double().reshape(Nt, -1)
+    ve = model.video_all_embs.double().reshape(Nv, -1)
+    S64 = (te / (te.norm(dim=1, keepdim=True) + 1e-13)) @ (ve / (ve.norm(dim=1, keepdim=True) + 1e-13)).T
+    want = 1 + ((S64 > S64[torch.arange(Nt), torch.as_tensor(gt, device=S64.device).long()][:, None]).sum(dim=1))
+    assert torch.equal(model.last_t2v_ranks.long(), want)
+    assert len(set(want.tolist())) > 50                       # degenerate, but the ranks are spread: equality is a real check
+    # with the list it asks for from the start nothing is retried
+    calls.clear()
+    monkeypatch.setattr(ops, 'default_pair_cap', lambda n: 1 << 20)
+    model.retrieve(tl, vl, precision='fp16')
+    assert len(calls) == 1 and calls[0][2] is False
+    assert torch.equal(model.last_t2v_ranks.long(), want)
