@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 17
+#define LAFF_ABI_VERSION 18
 
 enum {
     LAFF_OK = 0,
@@ -279,6 +279,12 @@ int laff_sim_gemm(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, i
  * laff_sim_gemm adds into (saves a fill launch). */
 int laff_row_dot_gt(laff_ctx* ctx, const void* T, const void* V, int Nt, int Nv, int K, float scale, int precision,
                     const int* gt_col, int col0, float* s_gt, int* zero_count);
+
+/* Host-side helper (no device work, any thread): owner[t] = position in the video id list of the prefix of caption id t before its first
+ * '#' -- the match predictor.py:241 makes per query (`txt_id.split('#')[0]` looked up in vis_ids).  Both id lists arrive as one UTF-8 blob
+ * each, ids separated by '\n', no trailing separator (ids must not contain '\n').  LAFF_E_SHAPE + message when a video id occurs twice
+ * or a caption names a video that is not there. */
+int laff_match_ids(const char* txt_blob, size_t txt_bytes, int n_txt, const char* vis_blob, size_t vis_bytes, int n_vis, int* owner /*host*/);
 
 /* laff_rank_prepare for ONE side of a sharded pass (laff_amd/dist.py 'video16': the 16-bit text operand is what is all-gathered, the
  * fp32 text rows stay with their owner):

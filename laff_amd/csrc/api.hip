@@ -401,6 +401,58 @@ int laff_fc_act_bn_fused_grouped(laff_ctx* ctx, const laff_fc_fused_problem* pro
     return LAFF_OK;
 }
 
+/* host-side helper, no device work: owner[t] = position in the video id list of the prefix of caption id t before its first '#'
+ * (predictor.py:241: txt_id.split('#')[0] looked up in vis_ids).  One open-addressing table over the video ids, FNV-1a. */
+int laff_match_ids(const char* txt_blob, size_t txt_bytes, int n_txt, const char* vis_blob, size_t vis_bytes, int n_vis, int* owner) {
+    if (n_txt < 0 || n_vis < 0 || (n_txt && (!txt_blob || !owner)) || (n_vis && !vis_blob)) return fail(LAFF_E_ARG, "laff_match_ids: bad arguments");
+    if (n_txt == 0) return LAFF_OK;
+    auto hash = [](const char* p, size_t n) {
+        unsigned long long h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+        return h;
+    };
+    size_t cap = 16;
+    while (cap < 2 * (size_t)n_vis + 2) cap <<= 1;
+    struct Slot { const char* p; unsigned len; int idx; };
+    std::vector<Slot> table(cap, Slot{nullptr, 0u, -1});
+    size_t at = 0;
+    for (int v = 0; v < n_vis; ++v) {
+        if (at > vis_bytes) return fail(LAFF_E_ARG, "laff_match_ids: the video blob holds fewer than %d ids", n_vis);
+        const char* b = vis_blob + at;
+        const char* e = (const char*)memchr(b, '\n', vis_bytes - at);
+        const size_t len = e ? (size_t)(e - b) : vis_bytes - at;
+        at += len + 1;
+        size_t s = hash(b, len) & (cap - 1);
+        while (table[s].idx >= 0) {
+            if (table[s].len == len && memcmp(table[s].p, b, len) == 0)
+                return fail(LAFF_E_SHAPE, "laff_match_ids: video id '%.*s' appears twice in vis_ids", (int)len, b);
+            s = (s + 1) & (cap - 1);
+        }
+        table[s] = Slot{b, (unsigned)len, v};
+    }
+    if (at != vis_bytes + 1 && !(n_vis == 0 && vis_bytes == 0)) return fail(LAFF_E_ARG, "laff_match_ids: the video blob does not hold exactly %d ids", n_vis);
+    at = 0;
+    for (int t = 0; t < n_txt; ++t) {
+        if (at > txt_bytes) return fail(LAFF_E_ARG, "laff_match_ids: the caption blob holds fewer than %d ids", n_txt);
+        const char* b = txt_blob + at;
+        const char* e = (const char*)memchr(b, '\n', txt_bytes - at);
+        const size_t line = e ? (size_t)(e - b) : txt_bytes - at;
+        at += line + 1;
+        const char* h = (const char*)memchr(b, '#', line);
+        const size_t len = h ? (size_t)(h - b) : line;
+        size_t s = hash(b, len) & (cap - 1);
+        int found = -1;
+        while (table[s].idx >= 0) {
+            if (table[s].len == len && memcmp(table[s].p, b, len) == 0) { found = table[s].idx; break; }
+            s = (s + 1) & (cap - 1);
+        }
+        if (found < 0) return fail(LAFF_E_SHAPE, "laff_match_ids: caption %d refers to a video that is not in vis_ids: '%.*s'", t, (int)len, b);
+        owner[t] = found;
+    }
+    if (at != txt_bytes + 1) return fail(LAFF_E_ARG, "laff_match_ids: the caption blob does not hold exactly %d ids", n_txt);
+    return LAFF_OK;
+}
+
 int laff_fc_strip_pack_bytes(int D, int Dk, size_t* out) {
     if (!out || D < 32 || (D & 31)) return fail(LAFF_E_SHAPE, "laff_fc_strip_pack_bytes: D must be a positive multiple of 32 (D=%d)", D);
     if (Dk != laff::FC_STRIP_K) return fail(LAFF_E_SHAPE, "laff_fc_strip_pack_bytes: the strip form takes Dk == 512 (Dk=%d)", Dk);

@@ -26,16 +26,19 @@ class _DS:
 
 
 class VisLoader:
+    """(the id strings exist before the loop starts, as in a Dataset: making them is not part of what is timed)"""
+
     def __init__(self, feats, bs):
         self.feats, self.bs = feats, bs
         self.n = next(iter(feats.values())).shape[0]
         self.dataset = _DS(self.n)
+        self.ids = ['video%d' % i for i in range(self.n)]
 
     def __iter__(self):
         for s in range(0, self.n, self.bs):
             e = min(self.n, s + self.bs)
             yield {'vis_feat_dict': {k: v[s:e] for k, v in self.feats.items()}, 'idxs': list(range(s, e)),
-                   'vis_ids': tuple('video%d' % i for i in range(s, e)), 'vis_frame_feat_dict': {}}
+                   'vis_ids': tuple(self.ids[s:e]), 'vis_frame_feat_dict': {}}
 
 
 class TxtLoader:
@@ -43,11 +46,12 @@ class TxtLoader:
         self.feats, self.gt, self.bs = feats, gt, bs
         self.n = next(iter(feats.values())).shape[0]
         self.dataset = _DS(self.n)
+        self.ids = ['video%d#%d' % (gt[i], i) for i in range(self.n)]
 
     def __iter__(self):
         for s in range(0, self.n, self.bs):
             e = min(self.n, s + self.bs)
-            ids = tuple('video%d#%d' % (self.gt[i], i) for i in range(s, e))
+            ids = tuple(self.ids[s:e])
             cap = {'caption': list(ids)}
             cap.update({k: v[s:e] for k, v in self.feats.items()})
             yield cap, list(range(s, e)), ids
@@ -80,6 +84,15 @@ def main():
     model.coalesce_loader_batches = True
     b = timed(lambda: model.retrieve(tl, vl))
     c = timed(lambda: model.predict(tl, vl, 'cosine'))
+    if os.environ.get('PREDICT_WALL_PROFILE'):
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        model.retrieve(tl, vl)
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
     print('%s, loader batches of %d (%d + %d batches), fp16 similarity operands, exact ranks:' % (name, bs, (Nt + bs - 1) // bs, (Nv + bs - 1) // bs))
     print('retrieve(), one launch set per batch (the reference loop shape)  %9.2f ms  %.3e pairs/s' % (a, Nt * Nv / a * 1e3))
     print('retrieve(), batches coalesced (default)                          %9.2f ms  %.3e pairs/s' % (b, Nt * Nv / b * 1e3))
