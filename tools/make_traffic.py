@@ -14,7 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from laff_amd.build import source_hash  # noqa: E402
 
-ENTRY = [('sim_strip_kernel', 'sim_gemm'), ('gemm_nt_x3_fused_grouped_kernel', 'fc_act_bn'), ('gemm_nt_x3_grouped_kernel', 'fc_act_bn'), ('gemm_nt_grouped_kernel', 'fc_act_bn'), ('gemm_nt_x3_kernel', 'sim_gemm'),
+ENTRY = [('sim_strip_kernel', 'sim_gemm'), ('fc_strip_kernel', 'fc_act_bn'), ('fc_strip_pack_kernel', 'fc_strip_pack'), ('rank_export_kernel', 'rank_export'), ('gemm_nt_x3_fused_grouped_kernel', 'fc_act_bn'), ('gemm_nt_x3_grouped_kernel', 'fc_act_bn'), ('gemm_nt_grouped_kernel', 'fc_act_bn'), ('gemm_nt_x3_kernel', 'sim_gemm'),
          ('gemm_nt_kernel', 'sim_gemm'), ('split_rows_kernel', 'split_rows'), ('fuse_reg_kernel', 'fuse'), ('fuse_stream_kernel', 'fuse'),
          ('frame_fuse_kernel', 'frame_fuse'), ('row_dot_gt_kernel', 'row_dot_gt'), ('fc_gather_kernel', 'fc_gather'),
          ('rank_metrics_kernel', 'rank_metrics'), ('pack_rows_kernel', 'pack_rows'), ('rank_prepare_kernel', 'rank_prepare'),

@@ -5,7 +5,7 @@
 #   3. the un-profiled bench line                                     -> profiles/<tag>_bench_line.json
 # Counter passes never combine --pmc with a trace domain (MI355X_MICROARCH.md; the pool refuses that combination).
 set -e
-TAG=${1:-r2}
+TAG=${1:-r4}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
