@@ -121,7 +121,10 @@ __device__ __forceinline__ void dma_piece(unsigned lane16, u32x4 rsrc, unsigned 
 // immediate offset: the instruction's offset field moves the LDS address as well as the global one.)
 template <int LDSOFF>
 __device__ __forceinline__ void dma_rows(unsigned voff, unsigned long long base, unsigned m0base) {
-    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+#ifndef LAFF_FCS_XFLAVOR
+#define LAFF_FCS_XFLAVOR ""
+#endif
+    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 " LAFF_FCS_XFLAVOR
                  ::"v"(voff), "s"(base), "s"(m0base), "n"(LDSOFF) : "memory", "scc");
 }
 // 16 bytes of the LDS staging -> a[R .. R + 3]
