@@ -37,13 +37,6 @@
 #include "kernels.h"
 #include "strip_util.h"
 
-// 1: every body issues one L2 prefetch instruction over the next strip's rows.  Measured at the C4 group (tools/debug/trace_fc_strip.py):
-// the next segment's strip load drops from 13.2k to 8.4k cycles, but an instruction that touches 64 lines costs ~265 cycles of the
-// body it sits in (+8.5k per strip): a net loss, off.
-#ifndef LAFF_FCS_PREFETCH
-#define LAFF_FCS_PREFETCH 0
-#endif
-
 namespace laff {
 
 namespace {
@@ -110,11 +103,10 @@ __device__ __forceinline__ void lds_read128(u32x4& d, unsigned addr) {
 }
 
 // one 1 KiB piece of the W stream, straight into LDS (lane L lands at M0 base + 16 L; the image is already in LDS order)
-template <int LDSOFF, int SRCOFF>
-__device__ __forceinline__ void dma_piece(unsigned lane16, u32x4 rsrc, unsigned soff, unsigned m0base) {
-    unsigned t;
-    asm volatile("v_add_u32 %0, %6, %1\n\ts_add_i32 m0, %4, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
-                 : "=&v"(t) : "v"(lane16), "s"(rsrc), "s"(soff), "s"(m0base), "n"(LDSOFF), "n"(SRCOFF) : "memory", "scc");
+template <int LDSOFF>
+__device__ __forceinline__ void dma_piece(unsigned voff, u32x4 rsrc, unsigned soff, unsigned m0base) {
+    asm volatile("s_add_i32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 ::"v"(voff), "s"(rsrc), "s"(soff), "s"(m0base), "n"(LDSOFF) : "memory", "scc");
 }
 
 // 1 KiB of input rows straight into LDS (lane L lands at M0 base + LDSOFF + 16 L): scalar base + per-lane 32-bit offset.  (No
@@ -148,16 +140,6 @@ __device__ __forceinline__ int split_exponent(float m) {
     return max(be - 127, -100);
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
-// L2 prefetch of the NEXT strip: one dword per lane, 64 different 128-byte lines per instruction (line 64 i + lane of this wave's 512:
-// row 4 i + (lane >> 4), segment lane & 15); the value is never used.  (Rows beyond the matrix touch the last row.)  `sink` is
-// read-write so that it stays ONE live register from the first prefetch to the segment's end: as a plain output every statement's
-// destination is dead at once for hipcc, which hands the register to something else while the load is still in flight.
-__device__ __forceinline__ void prefetch_lines(unsigned& sink, unsigned v_row, unsigned v_seg128, unsigned s_4i, unsigned s_maxrow, unsigned s_ldx4,
-                                               unsigned long long base) {
-    unsigned t;
-    asm volatile("v_add_u32 %1, %4, %2\n\tv_min_u32 %1, %5, %1\n\tv_mad_u32_u24 %1, %1, %6, %3\n\tglobal_load_dword %0, %1, %7"
-                 : "+v"(sink), "=&v"(t) : "v"(v_row), "v"(v_seg128), "s"(s_4i), "s"(s_maxrow), "s"(s_ldx4), "s"(base) : "memory");
-}
 // one raw chunk (two quads from the staging read-back) -> a[R .. R + 7], its eight values folded into the two running row maxima
 template <int R>
 __device__ __forceinline__ void stash_chunk(const u32x4& q0, const u32x4& q1, float& m0, float& m1) {
@@ -238,8 +220,9 @@ constexpr EpiStream make_stream() {
 //   * in front of sub-step BAR_J: counted vmcnt (this wave's pieces of the next slot have landed) + s_barrier (everybody's have, and
 //     everybody is done with the previous slot, which the pieces issued right behind the barrier refill -- 4 slots: 3 ahead);
 //   * (BAR_J .. BAR_J + 3, M = 1, 2): the 8 DMA pieces;  (H = 0, J = 0, M = 1): this block's four lane constants (one 16-byte load);
-//   * (J = 14, M = 1): one L2 PREFETCH instruction over the NEXT strip's rows (64 lines; the last ten bodies of a strip walk its 512
-//     lines per wave, earlier ones re-touch the first 64): the strip load of the next segment then runs at L2 latency;
+//     -- in the LAST THREE bodies of a segment those pieces would fetch W slots beyond it: they carry the first three K-eighth rounds
+//     of the NEXT strip's input rows instead (same count, same LDS targets: this wave's 8 KiB of the slot being freed), so that the
+//     strip switch starts with 24 of its 64 KiB per wave already in LDS;
 //   * everything else: the epilogue stream of the previous block, spread evenly (cost-weighted).  It starts behind the third MFMA
 //     of the block (the previous block's last MFMA has retired by then) and ends before the block does.
 constexpr int slot_piece(int sg) {
@@ -248,7 +231,6 @@ constexpr int slot_piece(int sg) {
     return -1;
 }
 constexpr bool slot_cvload(int sg) { return sg == 1; }
-constexpr bool slot_prefetch(int sg) { return sg % 48 == 3 * 14 + 1; }      // (J = 14, M = 1): behind the body's DMA pieces
 struct Plan {
     short begin[NSLOT + 1];
     short vm_bar[2];      // vmcnt operand at the barrier of body H
@@ -281,7 +263,6 @@ constexpr Plan make_plan() {
             const int H = sg / 48, J = (sg % 48) / 3, M = sg % 3;
             if (J == BAR_J && M == 0) bar_at[blk][H] = vm_n;
             if (slot_cvload(sg)) cv_ord[blk] = ++vm_n;
-            if (slot_prefetch(sg) && LAFF_FCS_PREFETCH) ++vm_n;
             if (slot_piece(sg) >= 0) { ++vm_n; last_piece[blk][H] = vm_n; }
             for (int i = p.begin[sg]; i < p.begin[sg + 1]; ++i) {
                 if (st.op[i].kind == OP_WAITCV) waitcv_at[blk] = vm_n;
@@ -325,12 +306,9 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
     const unsigned xa0 = lds0 + lane16, xa1 = lds0 + lane16 + 2u * SLOT;      // fragment addresses: ring slots 0, 1 | 2, 3
     const unsigned wslot = (unsigned)wave * (PIECES * 1024u);                   // this wave's 8 KiB of a slot (LDS and source offset)
     const unsigned ldsw = pin_s(lds0 + wslot);                                  // LDS address of this wave's 8 KiB of ring slot 0
-    const unsigned stg = pin_s(lds0 + (unsigned)wave * (unsigned)SLOT);         // strip staging: this wave's QUARTER of the (idle) ring
     const unsigned cvoff = (unsigned)n31 * 16u;
     float* const rsb = (float*)(smem + RS_OFF) + wave * 32;                     // this wave's 32 row scales (wave-private exchange)
-    unsigned pf_row = (unsigned)wave * 32u + ((unsigned)lane >> 4), pf_seg128 = ((unsigned)lane & 15u) * 128u;       // prefetch: lane -> (row, segment)
-    asm volatile("" : "+v"(pf_row), "+v"(pf_seg128));
-    unsigned pf_sink = 0u;
+    int pre_base = -1;           // >= 0: the previous segment's last three bodies brought rounds 0..2 of this segment's strip into buffers (e + pre_base) & 3
     const unsigned m0_keep = m0_get();
 #ifdef LAFF_FCS_TRACE
     // debug build: cycle stamps of wave 0 -- per segment s (up to 8): base 8 s: +0 start, +1 strip in the registers (raw), +2 row maxima,
@@ -356,8 +334,28 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
 #ifdef LAFF_FCS_TRACE
         if (trc && tid == 0 && trc_seg < 8) trc[64 + trc_seg] = (unsigned long long)n;
 #endif
-        // the strip this segment's bodies prefetch: the next segment's (this one's own when there is none: valid memory, harmless)
-        const bool has_next = u0 < u1;
+        // Input rows travel in K-eighth ROUNDS: 32 rows x 256 bytes per wave = 8 LDS-DMA instructions of 4 rows x 256 contiguous bytes
+        // (direct 16-byte loads in the fragment layout touch 32 rows per instruction and run at a fifth of the rate).  Instruction t, lane
+        // L: row 4 t + (L >> 4) of the wave's 32, LDS position L & 15 of that row <- source piece (L & 15) ^ (row & 15): the swizzle makes
+        // the fragment-order read-back conflict-free.  xoff(p, strip, xv): the per-lane source offsets (rows beyond the matrix read the
+        // last row), relative to the strip's first row.
+        auto xoff = [&](int p_, int strip_, unsigned (&xv)[8]) {
+            const int N_ = a.p[p_].N, ldx_ = a.p[p_].ldx, r0_ = strip_ * FR;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));              // made here: hipcc hoists lane-only terms out of the segment loop and keeps them all the way
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int rw = 4 * t + (ln >> 4);                       // row of the wave
+                const int r = std::min(r0_ + wave * 32 + rw, N_ - 1) - r0_;
+                xv[t] = (unsigned)r * (unsigned)ldx_ * 4u + ((((unsigned)ln & 15u) ^ ((unsigned)rw & 15u)) << 4);
+            }
+        };
+        // the strip whose first three rounds this segment's last three bodies bring in: the next segment's (n >= 2: three bodies exist)
+#ifdef LAFF_FCS_NOEARLY
+        const bool has_next = false;
+#else
+        const bool has_next = u0 < u1 && n >= 2;
+#endif
         int p2 = p, strip2 = strip;
         if (has_next) {
             p2 = 0;
@@ -365,14 +363,16 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             p2 = __builtin_amdgcn_readfirstlane(p2);
             strip2 = __builtin_amdgcn_readfirstlane((u0 - a.p[p2].unit0) / nblk);
         }
-        const unsigned pf_ldx4 = pin_s((unsigned)a.p[p2].ldx * 4u);
-        const unsigned pf_maxrow = pin_s((unsigned)(a.p[p2].N - 1 - strip2 * FR));
-        const unsigned long long pf_base = pin_s((unsigned long long)a.p[p2].X + (unsigned long long)(strip2 * FR) * (unsigned)a.p[p2].ldx * 4ull);
-        int pf_i = std::min(10 - 2 * n, 0);              // body k prefetches line set clamp(k + pf_i, 0, 7): the last ten bodies walk all eight
+        unsigned xvn[8];
+        xoff(p2, strip2, xvn);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) asm volatile("" : "+v"(xvn[t]));
+        const u32x4 rsrcXn = rebased_rsrc((unsigned long long)a.p[p2].X + (unsigned long long)(strip2 * FR) * (unsigned)a.p[p2].ldx * 4ull,
+                                          (unsigned long long)FR * (unsigned)a.p[p2].ldx * 4ull, 0ull);
         const int N = pin_s(a.p[p].N), ldx = pin_s(a.p[p].ldx), ldy = pin_s(a.p[p].ldy);
         const unsigned long long pX = pin_s((unsigned long long)a.p[p].X), pW = pin_s((unsigned long long)a.p[p].img);
         const unsigned long long pVec = pin_s((unsigned long long)a.p[p].vec), pY = pin_s((unsigned long long)a.p[p].Y);
-        const int row0 = strip * FR, row_w = row0 + wave * 32;
+        const int row0 = strip * FR;
 
         f32x16 acc[2];
         u32x4 fr[NSETS][2];
@@ -382,73 +382,69 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         f32x4 cv[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 
         int e_row = 0;                   // exponent of this lane's row maximum: scale 2^(9 - e) in, 2^(e - 9) out
-        // ---- the strip: this wave's 32 rows x 512 fp32 -> a[0:255].  The rows come in by LDS-DMA, 2 rows x 512 contiguous bytes per
-        // instruction (direct 16-byte loads in the fragment layout touch 32 rows per instruction and run at a fifth of the rate), in four
-        // rounds of one K quarter each (16 KiB) through two buffers in this wave's quarter of the idle ring; the source piece is
-        // swizzled (piece ^ (row & 15)) so that the fragment-order read-back -- lane (row n31, half hh) takes 16-byte pieces 4 cc + hh and
-        // 4 cc + 2 + hh of chunk cc -- is conflict-free, and that read-back goes straight into the accumulator registers. ----
+        // ---- the strip: this wave's 32 rows x 512 fp32 -> a[0:255] (raw), eight rounds through four wave-private buffers -- this wave's
+        // 8 KiB of each (idle) ring slot; round e lives in buffer (e + base) & 3.  Rounds 0..2 are already there when the previous
+        // segment's last bodies brought them (pre_base); up to four rounds are in flight.  The read-back (lane (row n31, half hh) takes
+        // 16-byte pieces 4 cc + hh and 4 cc + 2 + hh of chunk cc) folds the row maxima and parks the raw values in the accumulator file.
         {
             const unsigned long long xbase = pX + (unsigned long long)row0 * (unsigned)ldx * 4ull;
-            // instruction t of a round: rows 2 t + (lane >> 5), LDS position (lane & 31) <- source piece (lane & 31) ^ (row & 15)
-            unsigned sv[16];
-            const unsigned base_x = ((unsigned)lane & 31u) ^ (unsigned)hh;
+            unsigned xv[8];
+            xoff(p, strip, xv);
+            const bool pre = pre_base >= 0;
+            const int base = pre ? pre_base : 0;
+            unsigned XA[8];                            // read-back addresses inside a buffer: (cc, quad) -> piece 4 cc + 2 quad + hh, swizzled
+            {
+                unsigned ln = (unsigned)lane;
+                asm volatile("" : "+v"(ln));
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int r = std::min(row_w + 2 * t + hh, N - 1) - row0;
-                sv[t] = (unsigned)r * (unsigned)ldx * 4u + ((base_x ^ (unsigned)((2 * t) & 15)) << 4);
+                for (int j = 0; j < 8; ++j)
+                    XA[j] = (ln & 31u) * 256u + ((((unsigned)(4 * (j >> 1) + 2 * (j & 1)) + (ln >> 5)) ^ (ln & 15u)) << 4);
             }
-            // read-back addresses: piece = 4 cc + 2 quad + hh (cc = chunk within the quarter): the low four bits take the swizzle
-            unsigned XA[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                XA[j] = stg + (unsigned)n31 * 512u + ((((unsigned)(4 * (j >> 1) + 2 * (j & 1) + hh)) ^ ((unsigned)n31 & 15u)) << 4);
-            auto issue_round = [&](auto QC) {
-                constexpr int q = decltype(QC)::value;
-                const unsigned long long qbase = xbase + (unsigned long long)(q * 512);
-                static_for<0, 16>([&](auto TC) {
+            auto buf_of = [&](int e) { return ldsw + (unsigned)((e + base) & 3) * (unsigned)SLOT; };
+            auto issue_round = [&](auto EC) {
+                constexpr int e = decltype(EC)::value;
+                const unsigned long long ebase = xbase + (unsigned long long)(e * 256);
+                const unsigned b = pin_s(buf_of(e));
+                static_for<0, 8>([&](auto TC) {
                     constexpr int t = decltype(TC)::value;
-                    dma_rows<(q & 1) * 16384 + t * 1024>(sv[t], qbase, stg);
+                    dma_rows<t * 1024>(xv[t], ebase, b);
                 });
             };
             float m0 = 0.f, m1 = 0.f;                  // running maxima of |x| over this lane's half of its row
-            u32x4 rq[16];
-            auto read_round = [&](auto QC) {
-                // the round's 8 chunks: 16 reads into registers, then each chunk goes to its accumulator registers (raw) while its
-                // values are folded into the row maxima -- VALU work in the shadow of the next round's flight
-                constexpr int q = decltype(QC)::value;
-                static_for<0, 8>([&](auto CC) {
-                    constexpr int cc = decltype(CC)::value;
-                    constexpr int IMM = (q & 1) * 16384 + 256 * (cc >> 2);
-                    lds_read128<IMM>(rq[2 * cc], XA[2 * (cc & 3)]);
-                    lds_read128<IMM>(rq[2 * cc + 1], XA[2 * (cc & 3) + 1]);
-                });
+            u32x4 rq[8];
+            auto read_round = [&](auto EC) {
+                constexpr int e = decltype(EC)::value;
+                const unsigned b = buf_of(e);
+                static_for<0, 8>([&](auto JC) { constexpr int j = decltype(JC)::value; lds_read128<0>(rq[j], XA[j] + b); });
                 wait_lgkm<0>();
-                static_for<0, 16>([&](auto IC) { pin_v(rq[decltype(IC)::value]); });
+                static_for<0, 8>([&](auto IC) { pin_v(rq[decltype(IC)::value]); });
             };
-            auto stash_round = [&](auto QC) {
-                constexpr int q = decltype(QC)::value;
-                static_for<0, 8>([&](auto CC) {
+            auto stash_round = [&](auto EC) {
+                constexpr int e = decltype(EC)::value;
+                static_for<0, 4>([&](auto CC) {
                     constexpr int cc = decltype(CC)::value;
-                    stash_chunk<8 * (8 * q + cc)>(rq[2 * cc], rq[2 * cc + 1], m0, m1);
+                    stash_chunk<8 * (4 * e + cc)>(rq[2 * cc], rq[2 * cc + 1], m0, m1);
                 });
             };
-            using Q0 = std::integral_constant<int, 0>;
-            using Q1 = std::integral_constant<int, 1>;
-            using Q2 = std::integral_constant<int, 2>;
-            using Q3 = std::integral_constant<int, 3>;
-            issue_round(Q0{});
-            issue_round(Q1{});
-            wait_vm<16>();
-            read_round(Q0{}); issue_round(Q2{}); stash_round(Q0{});
-            wait_vm<16>();
-            read_round(Q1{}); issue_round(Q3{}); stash_round(Q1{});
-            wait_vm<16>();
-            read_round(Q2{}); stash_round(Q2{});
-            wait_vm<0>();
-            read_round(Q3{}); stash_round(Q3{});
+            using E0 = std::integral_constant<int, 0>; using E1 = std::integral_constant<int, 1>; using E2 = std::integral_constant<int, 2>;
+            using E3 = std::integral_constant<int, 3>; using E4 = std::integral_constant<int, 4>; using E5 = std::integral_constant<int, 5>;
+            using E6 = std::integral_constant<int, 6>; using E7 = std::integral_constant<int, 7>;
+            if (!pre) { issue_round(E0{}); issue_round(E1{}); issue_round(E2{}); }
+            issue_round(E3{});
+            // (the waits are those of the case without early rounds; with them rounds 0..2 landed before the previous segment ended and
+            // fewer operations are outstanding: the same operands pass at once)
+            wait_vm<24>(); read_round(E0{}); issue_round(E4{}); stash_round(E0{});
+            wait_vm<24>(); read_round(E1{}); issue_round(E5{}); stash_round(E1{});
+            wait_vm<24>(); read_round(E2{}); issue_round(E6{}); stash_round(E2{});
+            wait_vm<24>(); read_round(E3{}); issue_round(E7{}); stash_round(E3{});
+            wait_vm<24>(); read_round(E4{}); stash_round(E4{});
+            wait_vm<16>(); read_round(E5{}); stash_round(E5{});
+            wait_vm<8>(); read_round(E6{}); stash_round(E6{});
+            wait_vm<0>(); read_round(E7{}); stash_round(E7{});
             float m = fmaxf(m0, m1);
             m = fmaxf(m, __shfl_xor(m, 32));           // a row lives in lanes l and l + 32
             e_row = split_exponent(m);
+            pre_base = has_next ? ((n & 1) ? 2 : 0) : -1;   // where this segment's last three bodies will leave the next strip's rounds 0..2
         }
         __builtin_amdgcn_s_barrier();            // every wave has emptied its staging quarter: the ring may fill
         asm volatile("" ::: "memory");
@@ -462,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             constexpr int s = decltype(SC)::value;
             static_for<0, PIECES>([&](auto PC) {
                 constexpr int P = decltype(PC)::value;
-                dma_piece<s * SLOT + P * 1024, P * 1024>(lane16, rsrcW, std::min(soffW, img_bytes - SLOT), ldsw);
+                dma_piece<s * SLOT + P * 1024>(lane16 + (unsigned)(P * 1024), rsrcW, std::min(soffW, img_bytes - SLOT), ldsw);
             });
             soffW += SLOT;
         });
@@ -520,7 +516,9 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             constexpr EpiOp op = STREAM.op[decltype(IC)::value];
             constexpr int i = op.elem;
             if constexpr (op.kind == OP_WAITCV) {
-                if constexpr (decltype(DRAIN)::value) wait_vm<0>(); else wait_vm<PLAN.vm_cv>();
+                // (drain: the lane constants were the block's first vector-memory operation: 16 pieces and 16 stores came behind them --
+                // a vmcnt(0) here would also wait for the next strip's rows the last bodies have just asked for)
+                if constexpr (decltype(DRAIN)::value) wait_vm<32>(); else wait_vm<PLAN.vm_cv>();
                 asm volatile("" : "+v"(cv[Q]));
             } else if constexpr (op.kind == OP_MUL) {
                 asm volatile("v_mul_f32 %0, %1, %2" : "=v"(tt[i & 7]) : "v"(acc[Q][i]), "v"(rs[i]));
@@ -542,8 +540,9 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         };
 
         // ---- one body: half a column block (ring slot 2 PAR + H), see "the schedule of one column block" --------------------------------
-        auto body = [&](auto PARC, auto HC, int blk) {
+        auto body = [&](auto PARC, auto HC, auto XRC, int blk) {
             constexpr int PAR = decltype(PARC)::value, H = decltype(HC)::value, Q = PAR ^ 1;
+            constexpr int XR = decltype(XRC)::value;                 // >= 0: the pieces carry round XR of the next strip's rows, not the W stream
             constexpr int RSLOT = 2 * PAR + H;                                   // this body's ring slot
             constexpr int NSLOT_R = (RSLOT + 1) & 3;                             // the next body's
             constexpr int DSLOT = (RSLOT + 3) & 3;                               // the slot refilled here: the previous body's
@@ -585,12 +584,13 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                         const unsigned so = (unsigned)blk * 512u;
                         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(cv[PAR]) : "v"(cvoff), "s"(rsrcV), "s"(so) : "memory");
                     }
-                    if constexpr (slot_prefetch(SG) && LAFF_FCS_PREFETCH) {
-                        prefetch_lines(pf_sink, pf_row, pf_seg128, (unsigned)(4 * std::min(std::max(pf_i, 0), 7)), pf_maxrow, pf_ldx4, pf_base);
-                        ++pf_i;
-                    }
                     constexpr int dp = slot_piece(SG);
-                    if constexpr (dp >= 0) dma_piece<DSLOT * SLOT + dp * 1024, dp * 1024>(lane16, rsrcW, soff_here, ldsw);
+                    if constexpr (dp >= 0) {
+                        // the W stream's piece dp of the slot three ahead -- or, in the segment's last three bodies, instruction dp of round
+                        // XR of the next strip's rows; same LDS target either way
+                        if constexpr (XR >= 0) dma_piece<DSLOT * SLOT + dp * 1024>(xvn[dp], rsrcXn, (unsigned)(256 * XR), ldsw);
+                        else dma_piece<DSLOT * SLOT + dp * 1024>(lane16 + (unsigned)(dp * 1024), rsrcW, soff_here, ldsw);
+                    }
                     static_for<PLAN.begin[SG], PLAN.begin[SG + 1]>([&](auto IC) {
                         __builtin_amdgcn_sched_barrier(0);
                         epi_item(std::integral_constant<int, Q>{}, IC, std::false_type{});
@@ -602,6 +602,8 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
 
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using IM1 = std::integral_constant<int, -1>;
         auto drain = [&](auto QC, int blk) {
             STAMP(5);
             mfma_drain_nops();
@@ -609,32 +611,55 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             soffY = (unsigned)blk * 128u;
             static_for<0, STREAM.n>([&](auto IC) { epi_item(QC, IC, std::true_type{}); });
         };
+        // The segment's blocks: a plain loop, then -- when a next segment exists -- its last two blocks as the copies whose last three bodies
+        // fetch the next strip's first three rounds (compile-time copies: the plain loop keeps its one branch per two blocks).
+        auto plain = [&](auto PARC, int b) {
+            body(PARC, I0{}, IM1{}, blk0 + b);
+            body(PARC, I1{}, IM1{}, blk0 + b);
+        };
+        auto tail = [&](auto PARC, int b) {
+            constexpr int P = decltype(PARC)::value;
+            body(PARC, I0{}, IM1{}, blk0 + b);
+            body(PARC, I1{}, I0{}, blk0 + b);
+            rsrcYe = rsrcY;
+            body(std::integral_constant<int, P ^ 1>{}, I0{}, I1{}, blk0 + b + 1);
+            body(std::integral_constant<int, P ^ 1>{}, I1{}, I2{}, blk0 + b + 1);
+            drain(std::integral_constant<int, P ^ 1>{}, blk0 + b + 1);
+        };
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[1][e] = 0.0f;
         {
-            int b = 0;
+            const int m = has_next ? n - 2 : n;          // blocks of the plain loop
+            int b = 0, par = 0;                          // par: parity of the block behind the plain loop
+            if (m > 0) {
 #pragma nounroll
-            for (;;) {
-                body(I0{}, I0{}, blk0 + b);
-                body(I0{}, I1{}, blk0 + b);
-                rsrcYe = rsrcY;
-                if (++b >= n) { drain(I0{}, blk0 + b - 1); break; }
-                body(I1{}, I0{}, blk0 + b);
-                body(I1{}, I1{}, blk0 + b);
-                if (++b >= n) { drain(I1{}, blk0 + b - 1); break; }
+                for (;;) {
+                    plain(I0{}, b);
+                    rsrcYe = rsrcY;
+                    if (++b >= m) { par = 1; break; }
+                    plain(I1{}, b);
+                    if (++b >= m) { par = 0; break; }
+                }
+            }
+            if (has_next) {
+                if (par == 0) tail(I0{}, b); else tail(I1{}, b);
+            } else {
+                if (par == 1) drain(I0{}, blk0 + b - 1); else drain(I1{}, blk0 + b - 1);
             }
         }
-        // segment end: nothing of this wave may still be in flight towards LDS or the fragment registers
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // segment end: nothing of this wave may still be in flight towards the fragment registers.  (Vector memory is NOT drained: the
+        // stores need no wait, and the pieces in flight -- the next strip's first rounds -- go to this wave's own parts of the ring, which
+        // nobody else touches before the barrier behind the next strip load, whose counted waits cover them.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int s8 = 0; s8 < NSETS; ++s8) asm volatile("" ::"v"(fr[s8][0]), "v"(fr[s8][1]));
-        asm volatile("" ::"v"(pf_sink));
         __builtin_amdgcn_s_barrier();            // every wave is done with the ring before the next segment's strip staging refills it
         STAMP(6);
 #ifdef LAFF_FCS_TRACE
         ++trc_seg;
 #endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA of this workgroup outlives it
     m0_set(m0_keep);
     agpr_hold_end(hold);
 #undef STAMP

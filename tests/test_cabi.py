@@ -127,7 +127,7 @@ def test_fc_strip_kernels_keep_out_of_the_accumulator_registers(tmp_path):
     assert len(stats) == 3                                    # the three epilogue kinds
     for name, st in stats.items():
         assert st['acc_outside'] == 0 and st['scratch'] == 0, (name, st)
-        assert st['mfma'] == 4 * 48, (name, st)
+        assert st['mfma'] == 12 * 48, (name, st)           # the plain loop's four bodies + two tails of four (fc_strip.hip)
     text = open(asm[0]).read()
     for name in stats:
         meta = text[text.index('.name:           ' + name):]

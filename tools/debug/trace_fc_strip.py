@@ -35,7 +35,7 @@ seg = a[:, :64].reshape(nwg, 8, 8)
 t0 = a[:, 0].min()
 ends = seg[:, :, 6].max(axis=1)
 print('kernel span (cycles): %d   starts spread %d   end spread %d' % (ends.max() - t0, a[:, 0].max() - t0, ends.max() - ends.min()))
-names = ['strip -> registers (raw)', 'row maxima', 'converted', 'ring prologue + barrier', 'block loop', 'drain + segment end']
+names = ['strip -> registers (raw) + barrier', 'W prologue issue', 'converted', 'prologue landed + barrier', 'block loop', 'drain + segment end']
 tot = np.zeros(6)
 nseg = nblk = 0
 for s in range(8):
