@@ -50,8 +50,8 @@ constexpr int SLOT = 32 * 1024;                // one ring slot: 32 columns x 25
 constexpr int PLANE = 16 * 1024;
 constexpr int RING = 4;
 constexpr int PIECES = 8;                      // 1 KiB LDS-DMA pieces per wave per slot
-constexpr int RS_OFF = RING * SLOT;            // per wave: 32 row scales (fp32)
-constexpr int SMEM = RS_OFF + 4 * 128;
+constexpr int XB_OFF = RING * SLOT;            // a fifth 32 KiB buffer, strip staging only (all of the CU's LDS: 160 KiB)
+constexpr int SMEM = XB_OFF + SLOT;
 static_assert(SMEM <= 160 * 1024, "LDS budget");
 
 constexpr int FD = 6;                          // fragment reads run FD sub-steps ahead,
@@ -219,15 +219,18 @@ constexpr EpiStream make_stream() {
 //   * (J, 0): the two fragment reads (hi, lo plane) of the sub-step FD ahead -- from J = BAR_J on that is the NEXT ring slot;
 //   * in front of sub-step BAR_J: counted vmcnt (this wave's pieces of the next slot have landed) + s_barrier (everybody's have, and
 //     everybody is done with the previous slot, which the pieces issued right behind the barrier refill -- 4 slots: 3 ahead);
-//   * (BAR_J .. BAR_J + 3, M = 1, 2): the 8 DMA pieces;  (H = 0, J = 0, M = 1): this block's four lane constants (one 16-byte load);
+//   * (BAR_J .. 15, M = 1) and two M = 2 slots: the 8 DMA pieces;  (H = 0, J = 0, M = 1): this block's four lane constants (one load);
 //     -- in the LAST THREE bodies of a segment those pieces would fetch W slots beyond it: they carry the first three K-eighth rounds
-//     of the NEXT strip's input rows instead (same count, same LDS targets: this wave's 8 KiB of the slot being freed), so that the
-//     strip switch starts with 24 of its 64 KiB per wave already in LDS;
+//     of the NEXT strip's input rows instead (same count, same LDS targets: this wave's 8 KiB of the slot being freed); the first of
+//     the three also issues round 3 into the staging-only fifth buffer, and round 4 goes into the last body's slot in front of the
+//     drain: the strip switch starts with 40 of its 64 KiB per wave in LDS or on the way;
 //   * everything else: the epilogue stream of the previous block, spread evenly (cost-weighted).  It starts behind the third MFMA
 //     of the block (the previous block's last MFMA has retired by then) and ends before the block does.
 constexpr int slot_piece(int sg) {
     const int J = (sg % 48) / 3, M = sg % 3;
-    if (M >= 1 && J >= BAR_J && J < BAR_J + 4) return 2 * (J - BAR_J) + (M - 1);
+    if (M == 1 && J >= BAR_J) return J - BAR_J;          // one per sub-step behind the barrier ...
+    if (M == 2 && J == BAR_J + 1) return 6;              // ... and two sub-steps with a second one: the four waves leave the barrier
+    if (M == 2 && J == BAR_J + 4) return 7;              // together, and pieces packed into four sub-steps queue up in the CU's one TA path
     return -1;
 }
 constexpr bool slot_cvload(int sg) { return sg == 1; }
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
 
     constexpr Plan PLAN = make_plan<ACTK>();
     constexpr EpiStream STREAM = make_stream<ACTK>();
+    constexpr int DRAIN_STORES = 16;                      // OP_ST items of the stream: what a drain leaves in the vector-memory queue
     static_assert(PLAN.fits, "the epilogue stream does not fit behind the MFMAs of one column block");
 
     // per-lane constants of the loops
@@ -307,7 +311,6 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
     const unsigned wslot = (unsigned)wave * (PIECES * 1024u);                   // this wave's 8 KiB of a slot (LDS and source offset)
     const unsigned ldsw = pin_s(lds0 + wslot);                                  // LDS address of this wave's 8 KiB of ring slot 0
     const unsigned cvoff = (unsigned)n31 * 16u;
-    float* const rsb = (float*)(smem + RS_OFF) + wave * 32;                     // this wave's 32 row scales (wave-private exchange)
     int pre_base = -1;           // >= 0: the previous segment's last three bodies brought rounds 0..2 of this segment's strip into buffers (e + pre_base) & 3
     const unsigned m0_keep = m0_get();
 #ifdef LAFF_FCS_TRACE
@@ -400,7 +403,14 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                 for (int j = 0; j < 8; ++j)
                     XA[j] = (ln & 31u) * 256u + ((((unsigned)(4 * (j >> 1) + 2 * (j & 1)) + (ln >> 5)) ^ (ln & 15u)) << 4);
             }
-            auto buf_of = [&](int e) { return ldsw + (unsigned)((e + base) & 3) * (unsigned)SLOT; };
+            // round -> buffer.  Without early rounds: 0 1 2 3 X 0 1 2 (five in flight).  With them: rounds 0..2 sit in ring slots b0 b1 b2
+            // (b_i = (i + base) & 3), round 3 in X, round 4 in b3 (the previous segment's last slot): b0 b1 b2 X b3 b0 b1 X -- round 7 follows
+            // round 3, which landed long ago, not round 2, the last one to have been issued.
+            auto buf_of = [&](int e) {
+                const int ring = pre ? (e < 3 ? e : (e == 4 ? 3 : e - 5)) : (e < 4 ? e : e - 5);
+                const bool x = pre ? (e == 3 || e == 7) : e == 4;
+                return ldsw + (unsigned)(x ? RING : ((ring + base) & 3)) * (unsigned)SLOT;
+            };
             auto issue_round = [&](auto EC) {
                 constexpr int e = decltype(EC)::value;
                 const unsigned long long ebase = xbase + (unsigned long long)(e * 256);
@@ -429,15 +439,24 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             using E0 = std::integral_constant<int, 0>; using E1 = std::integral_constant<int, 1>; using E2 = std::integral_constant<int, 2>;
             using E3 = std::integral_constant<int, 3>; using E4 = std::integral_constant<int, 4>; using E5 = std::integral_constant<int, 5>;
             using E6 = std::integral_constant<int, 6>; using E7 = std::integral_constant<int, 7>;
-            if (!pre) { issue_round(E0{}); issue_round(E1{}); issue_round(E2{}); }
-            issue_round(E3{});
-            // (the waits are those of the case without early rounds; with them rounds 0..2 landed before the previous segment ended and
-            // fewer operations are outstanding: the same operands pass at once)
-            wait_vm<24>(); read_round(E0{}); issue_round(E4{}); stash_round(E0{});
-            wait_vm<24>(); read_round(E1{}); issue_round(E5{}); stash_round(E1{});
-            wait_vm<24>(); read_round(E2{}); issue_round(E6{}); stash_round(E2{});
-            wait_vm<24>(); read_round(E3{}); issue_round(E7{}); stash_round(E3{});
-            wait_vm<24>(); read_round(E4{}); stash_round(E4{});
+            if (!pre) {
+                issue_round(E0{}); issue_round(E1{}); issue_round(E2{}); issue_round(E3{}); issue_round(E4{});
+                wait_vm<32>(); read_round(E0{}); issue_round(E5{}); stash_round(E0{});
+                wait_vm<32>(); read_round(E1{}); issue_round(E6{}); stash_round(E1{});
+                wait_vm<32>(); read_round(E2{}); issue_round(E7{}); stash_round(E2{});
+                wait_vm<32>(); read_round(E3{}); stash_round(E3{});
+                wait_vm<24>(); read_round(E4{}); stash_round(E4{});
+            } else {
+                // The queue holds, oldest first: round 3 and round 0 (tail body 1), round 1 (body 2: 8 pieces, 8 stores, the lane constants),
+                // round 2 (body 3: 8 + 8), round 4 (8, in front of the drain), the drain's stores.  The counts are lower bounds of what was
+                // issued behind the round waited for.
+                constexpr int DR = DRAIN_STORES;
+                wait_vm<17 + 16 + 8 + DR>(); read_round(E0{}); issue_round(E5{}); stash_round(E0{});
+                wait_vm<16 + 8 + DR + 8>(); read_round(E1{}); issue_round(E6{}); stash_round(E1{});
+                read_round(E3{}); issue_round(E7{}); stash_round(E3{});
+                wait_vm<8 + DR + 24>(); read_round(E2{}); stash_round(E2{});
+                wait_vm<24>(); read_round(E4{}); stash_round(E4{});
+            }
             wait_vm<16>(); read_round(E5{}); stash_round(E5{});
             wait_vm<8>(); read_round(E6{}); stash_round(E6{});
             wait_vm<0>(); read_round(E7{}); stash_round(E7{});
@@ -474,14 +493,10 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         asm volatile("s_nop 3" ::: "memory");            // v_accvgpr_write -> MFMA reading it
         STAMP(3);
         {
-            // the epilogue's row scales: lane (n31, hh) needs those of rows 8 q + 4 hh + e -- through LDS (wave-private)
-            if (hh == 0) rsb[n31] = pow2f(e_row - 9);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the epilogue's row scales: lane (n31, hh) needs those of rows 8 q + 4 hh + e, which lane 8 q + 4 hh + e has
+            const float mine = pow2f(e_row - 9);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 t = *(const float4*)(rsb + 8 * q + 4 * hh);
-                rs[4 * q] = t.x; rs[4 * q + 1] = t.y; rs[4 * q + 2] = t.z; rs[4 * q + 3] = t.w;
-            }
+            for (int i = 0; i < 16; ++i) rs[i] = __shfl(mine, 8 * (i >> 2) + 4 * hh + (i & 3));
         }
         // output addressing: row 8 q + 4 hh + e of the wave's 32 at voff0 + (8 q + e) ldy4
         const unsigned ldy4 = (unsigned)ldy * 4u;
@@ -511,6 +526,10 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         // ---- one micro-op of the epilogue of block `blk - 1` (accumulator set Q, lane constants cv[Q]) --------------------------------
         u32x4 rsrcYe = rsrcNone;            // the first body's epilogue runs on nothing: an empty buffer drops its stores
         unsigned soffY = 0u;
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using IM1 = std::integral_constant<int, -1>;
         auto epi_item = [&](auto QC, auto IC, auto DRAIN) {
             constexpr int Q = decltype(QC)::value;
             constexpr EpiOp op = STREAM.op[decltype(IC)::value];
@@ -518,7 +537,8 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             if constexpr (op.kind == OP_WAITCV) {
                 // (drain: the lane constants were the block's first vector-memory operation: 16 pieces and 16 stores came behind them --
                 // a vmcnt(0) here would also wait for the next strip's rows the last bodies have just asked for)
-                if constexpr (decltype(DRAIN)::value) wait_vm<32>(); else wait_vm<PLAN.vm_cv>();
+                // (a drain: the two bodies behind the load issued 2 x (8 pieces + 8 stores); DRAIN counts what else was)
+                if constexpr (decltype(DRAIN)::value >= 0) wait_vm<32 + decltype(DRAIN)::value>(); else wait_vm<PLAN.vm_cv>();
                 asm volatile("" : "+v"(cv[Q]));
             } else if constexpr (op.kind == OP_MUL) {
                 asm volatile("v_mul_f32 %0, %1, %2" : "=v"(tt[i & 7]) : "v"(acc[Q][i]), "v"(rs[i]));
@@ -553,7 +573,8 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                 constexpr int J = decltype(JC)::value;
                 constexpr int G = 16 * H + J;                                    // sub-step of the block: strip registers 8 G ..
                 if constexpr (J == BAR_J) {
-                    wait_vm<PLAN.vm_bar[H]>();
+                    // (the segment's last body has no next slot to wait for: what is in flight is the next strip's)
+                    if constexpr (XR != 2) wait_vm<PLAN.vm_bar[H]>();
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
@@ -584,6 +605,10 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                         const unsigned so = (unsigned)blk * 512u;
                         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(cv[PAR]) : "v"(cvoff), "s"(rsrcV), "s"(so) : "memory");
                     }
+                    if constexpr (XR == 0 && M == 1 && J < 8) {
+                        // round 3 of the next strip, to the staging-only buffer (no ring slot: no barrier to respect)
+                        dma_piece<XB_OFF + J * 1024>(xvn[J], rsrcXn, 3u * 256u, ldsw);
+                    }
                     constexpr int dp = slot_piece(SG);
                     if constexpr (dp >= 0) {
                         // the W stream's piece dp of the slot three ahead -- or, in the segment's last three bodies, instruction dp of round
@@ -593,23 +618,19 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
                     }
                     static_for<PLAN.begin[SG], PLAN.begin[SG + 1]>([&](auto IC) {
                         __builtin_amdgcn_sched_barrier(0);
-                        epi_item(std::integral_constant<int, Q>{}, IC, std::false_type{});
+                        epi_item(std::integral_constant<int, Q>{}, IC, IM1{});
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
         };
 
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        using IM1 = std::integral_constant<int, -1>;
-        auto drain = [&](auto QC, int blk) {
+        auto drain = [&](auto QC, auto EXTRA, int blk) {
             STAMP(5);
             mfma_drain_nops();
             rsrcYe = rsrcY;
             soffY = (unsigned)blk * 128u;
-            static_for<0, STREAM.n>([&](auto IC) { epi_item(QC, IC, std::true_type{}); });
+            static_for<0, STREAM.n>([&](auto IC) { epi_item(QC, IC, EXTRA); });
         };
         // The segment's blocks: a plain loop, then -- when a next segment exists -- its last two blocks as the copies whose last three bodies
         // fetch the next strip's first three rounds (compile-time copies: the plain loop keeps its one branch per two blocks).
@@ -624,7 +645,15 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             rsrcYe = rsrcY;
             body(std::integral_constant<int, P ^ 1>{}, I0{}, I1{}, blk0 + b + 1);
             body(std::integral_constant<int, P ^ 1>{}, I1{}, I2{}, blk0 + b + 1);
-            drain(std::integral_constant<int, P ^ 1>{}, blk0 + b + 1);
+            // Every wave is done with the ring (the segment's barrier, taken here instead of behind the drain): round 4 goes to the last
+            // body's slot and flies while the drain computes.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            static_for<0, 8>([&](auto TC) {
+                constexpr int t = decltype(TC)::value;
+                dma_piece<(2 * (P ^ 1) + 1) * SLOT + t * 1024>(xvn[t], rsrcXn, 4u * 256u, ldsw);
+            });
+            drain(std::integral_constant<int, P ^ 1>{}, std::integral_constant<int, 8>{}, blk0 + b + 1);
         };
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[1][e] = 0.0f;
@@ -644,7 +673,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
             if (has_next) {
                 if (par == 0) tail(I0{}, b); else tail(I1{}, b);
             } else {
-                if (par == 1) drain(I0{}, blk0 + b - 1); else drain(I1{}, blk0 + b - 1);
+                if (par == 1) drain(I0{}, I0{}, blk0 + b - 1); else drain(I1{}, I0{}, blk0 + b - 1);
             }
         }
         // segment end: nothing of this wave may still be in flight towards the fragment registers.  (Vector memory is NOT drained: the
@@ -653,7 +682,7 @@ __global__ __launch_bounds__(256, 1) void fc_strip_kernel(const FcStripArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int s8 = 0; s8 < NSETS; ++s8) asm volatile("" ::"v"(fr[s8][0]), "v"(fr[s8][1]));
-        __builtin_amdgcn_s_barrier();            // every wave is done with the ring before the next segment's strip staging refills it
+        if (!has_next) __builtin_amdgcn_s_barrier();   // every wave is done with the ring before the next segment's strip staging refills it
         STAMP(6);
 #ifdef LAFF_FCS_TRACE
         ++trc_seg;
