@@ -21,6 +21,7 @@ struct laff_ctx {
     unsigned metrics_slot = 0;     // every laff_rank_metrics_async call takes the next slot: calls captured into different graphs (or in
                                    // flight on different streams) do not share their result buffer
     double* h_metrics = nullptr;   // pinned host mirror
+    char* d_mscratch = nullptr;    // METRIC_SLOTS x rank_metrics_scratch_bytes(): the metrics kernel's partials + histograms, kept zero
 };
 
 namespace {
@@ -48,6 +49,17 @@ int hip_fail(hipError_t e, const char* what) {
         hipError_t e_ = (expr);                        \
         if (e_ != hipSuccess) return hip_fail(e_, #expr); \
     } while (0)
+
+int metrics_buffers(laff_ctx* ctx) {
+    if (ctx->d_metrics) return LAFF_OK;
+    const size_t sb = laff::rank_metrics_scratch_bytes();
+    HIP_TRY(hipMalloc((void**)&ctx->d_mscratch, METRIC_SLOTS * sb));
+    HIP_TRY(hipMemset(ctx->d_mscratch, 0, METRIC_SLOTS * sb));
+    HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&ctx->d_metrics, METRIC_SLOTS * 8 * sizeof(double)));
+    HIP_TRY(hipMemset(ctx->d_metrics, 0, METRIC_SLOTS * 8 * sizeof(double)));
+    return LAFF_OK;
+}
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -115,6 +127,7 @@ int laff_ctx_set_stream(laff_ctx* ctx, void* hip_stream) {
 int laff_ctx_destroy(laff_ctx* ctx) {
     if (ctx) {
         if (ctx->d_metrics) (void)hipFree(ctx->d_metrics);
+        if (ctx->d_mscratch) (void)hipFree(ctx->d_mscratch);
         if (ctx->h_metrics) (void)hipHostFree(ctx->h_metrics);
     }
     delete ctx;
@@ -901,13 +914,11 @@ int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, int base, i
     if (!rank1 || !out8) return fail(LAFF_E_ARG, "laff_rank_metrics_async: null argument");
     if (Nq < 1) return fail(LAFF_E_SHAPE, "laff_rank_metrics_async: Nq=%d", Nq);
     DeviceGuard g(ctx->device);
-    if (!ctx->d_metrics) {
-        HIP_TRY(hipMalloc((void**)&ctx->d_metrics, METRIC_SLOTS * 8 * sizeof(double)));
-        HIP_TRY(hipMemset(ctx->d_metrics, 0, METRIC_SLOTS * 8 * sizeof(double)));
-        HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
-    }
-    double* slot = ctx->d_metrics + 8 * (size_t)(1 + ctx->metrics_slot++ % (METRIC_SLOTS - 1));      // (slot 0: the synchronous call)
-    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, slot, slot + 7, ctx->stream));
+    if (int rc = metrics_buffers(ctx)) return rc;
+    const size_t si = 1 + ctx->metrics_slot++ % (METRIC_SLOTS - 1);                                  // (slot 0: the synchronous call)
+    double* slot = ctx->d_metrics + 8 * si;
+    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, slot, slot + 7,
+                                      (unsigned*)(ctx->d_mscratch + si * laff::rank_metrics_scratch_bytes()), ctx->stream));
     HIP_TRY(hipMemcpyAsync(out8, slot, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return LAFF_OK;
 }
@@ -917,12 +928,8 @@ int laff_rank_metrics(laff_ctx* ctx, const int* rank1, int Nq, int base, int* ra
     if (!rank1 || !out7) return fail(LAFF_E_ARG, "laff_rank_metrics: null argument");
     if (Nq < 1) return fail(LAFF_E_SHAPE, "laff_rank_metrics: Nq=%d", Nq);
     DeviceGuard g(ctx->device);
-    if (!ctx->d_metrics) {
-        HIP_TRY(hipMalloc((void**)&ctx->d_metrics, METRIC_SLOTS * 8 * sizeof(double)));
-        HIP_TRY(hipMemset(ctx->d_metrics, 0, METRIC_SLOTS * 8 * sizeof(double)));
-        HIP_TRY(hipHostMalloc((void**)&ctx->h_metrics, 8 * sizeof(double), hipHostMallocDefault));
-    }
-    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, ctx->d_metrics + 7, ctx->stream));
+    if (int rc = metrics_buffers(ctx)) return rc;
+    HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, ctx->d_metrics, ctx->d_metrics + 7, (unsigned*)ctx->d_mscratch, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->h_metrics, ctx->d_metrics, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->h_metrics[7] != 0.0)

@@ -36,6 +36,10 @@ __device__ __forceinline__ double exact_cos_with(LoadT&& load_t, const float* __
 #pragma unroll 8
         for (int c = sl * 4; c < d; c += RG * 4) {
             const float4 a = load_t(h, c), b = *(const float4*)(vh + c);
+#ifdef LAFF_EXACT_NOFMA
+            tt += (double)(a.x + a.y + a.z + a.w); vv += (double)(b.x + b.y + b.z + b.w); tv += 1.0;
+            continue;
+#endif
             const double ax = a.x, ay = a.y, az = a.z, aw = a.w, bx = b.x, by = b.y, bz = b.z, bw = b.w;
             tt = fma(ax, ax, tt); tt = fma(ay, ay, tt); tt = fma(az, az, tt); tt = fma(aw, aw, tt);
             vv = fma(bx, bx, vv); vv = fma(by, by, vv); vv = fma(bz, bz, vv); vv = fma(bw, bw, vv);

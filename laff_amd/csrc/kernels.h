@@ -204,7 +204,9 @@ hipError_t launch_rank_export(const double* s_gt64, int* count, float* S, int ld
                               int world, int col0, unsigned* out, unsigned cap, unsigned* fill, hipStream_t st);
 hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64, int* count,
                                float* S, int lds, unsigned* pairs, unsigned pair_cap, hipStream_t st);
-hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, hipStream_t st);
+// scratch: rank_metrics_scratch_bytes() bytes, zero before the first launch (every launch leaves it zero); not shared by launches in flight
+size_t rank_metrics_scratch_bytes();
+hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, unsigned* scratch, hipStream_t st);
 hipError_t launch_gather_gt(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt,
                             hipStream_t st);
 hipError_t launch_rank_count(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, const float* s_gt,

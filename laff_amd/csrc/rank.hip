@@ -353,7 +353,11 @@ __device__ __forceinline__ void resolve_groups(const float* __restrict__ Et, con
     const unsigned* entries = pairs + 4 + cnt_words;
     (void)pair_cap;
     auto one = [&](unsigned r, unsigned c, bool ok) {
+#ifdef LAFF_RESOLVE_HOTROWS
+        const double ex = exact_cos(Et + (long)(r & 63u) * K, Ev + (long)(c & 63u) * K, H, d, sl);
+#else
         const double ex = exact_cos(Et + (long)r * K, Ev + (long)c * K, H, d, sl);
+#endif
         const double sg = s_gt64[r];
         const bool above = ex > sg;
         if (ok && sl == 0) {
@@ -371,12 +375,14 @@ __device__ __forceinline__ void resolve_groups(const float* __restrict__ Et, con
     const unsigned group = (blockIdx.x * 256u + threadIdx.x) / RG, ngroups = gridDim.x * (256u / RG);
     unsigned qn = 0;                                                         // wave-uniform
     auto drain = [&]() {
+#ifndef LAFF_RESOLVE_SCAN_ONLY
         for (unsigned i = 0; i < qn; i += 4) {
             const unsigned j = i + sub;
             const bool ok = j < qn;
             const unsigned k = ok ? j : qn - 1;
             one(queue[wv][k][0], queue[wv][k][1], ok);
         }
+#endif
         qn = 0;
     };
     const unsigned long long trips = (slots + ngroups - 1) / ngroups;
@@ -645,42 +651,50 @@ hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv,
     return hipGetLastError();
 }
 
-// evaluation.eval (/root/reference/evaluation.py:92-109) for single-GT rows, on the device: one 1024-thread block.
+// evaluation.eval (/root/reference/evaluation.py:92-109) for single-GT rows, on the device.
 // out7 = r1, r5, r10, medr, meanr, mir, mAP (= mir).  err[0] = 1.0 (and NaN metrics) if a rank < 1 was seen, else 0.0.
-// The median is an order statistic of positive integers: MSB-first radix select with 8-bit digits, starting at the top
-// non-zero byte of the largest rank (two passes for ranks < 65536).  The digit histogram lives in LDS with every bin
-// REPLICATED 32 times (replica = lane & 31, row pitch 33 words): retrieval ranks pile up on a few values (41 % are rank 1
-// at C4) and 64 lanes adding to one LDS word serialise 64-deep -- a first radix version with plain bins took 72 us, a
-// 16-way value search without atomics 55 us (one workgroup = one CU: its VALU work does not spread), bisection 68 us.
-// One workgroup, ranks streamed from L2 each pass; all reductions of a phase share one barrier pair.
 // rank = r[i] + base (base = 1 turns the fused "better-scoring videos" counts into ranks); ranks_out, when given, receives them.
+//
+// Up to MS_GMAX blocks of 1024 threads, one rank per thread per trip (one workgroup is one CU: 40,000 reciprocals and histogram
+// updates on a single CU took 23-31 us).  Every block leaves its partial sums in its own slot of the scratch (reduced by the last
+// block in a fixed order: the fp64 reciprocal sum does not depend on arrival order) and adds two 256-bin histograms to the scratch
+// with integer atomics: lo[v] for v < 256, hi[v >> 8] (hi[255]: everything from 65,280 up).  The block that draws the last ticket
+// finishes: the median is an order statistic of positive integers -- retrieval ranks are small, so it usually falls into lo[] and
+// nothing is read again; otherwise hi[] fixes the top byte and ONE pass of that block over the ranks (MSB-first radix select with
+// 8-bit digits, histogram bins replicated 32 times in LDS: ranks pile up on a few values and 64 lanes adding to one LDS word
+// serialise) the low byte; ranks from 65,280 up take the general select from the top non-zero byte.  The last block clears the
+// scratch for the next launch.
+constexpr int MS_GMAX = 256;
+struct MetricsPartial { unsigned long long c1, c5, c10, sum; double isum; int mx, mn; int pad[4]; };      // 64 bytes
+static_assert(sizeof(MetricsPartial) == 64, "scratch layout");
+// scratch words: {ticket, 3 x pad} | lo[256] | hi[256] | pad to 4 KiB | MS_GMAX partials
+constexpr size_t MS_BYTES = 4096 + (size_t)MS_GMAX * sizeof(MetricsPartial);
+size_t rank_metrics_scratch_bytes() { return MS_BYTES; }
+
 __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, int base, int* __restrict__ ranks_out,
-                                                            double* __restrict__ out7, double* __restrict__ err) {
+                                                            double* __restrict__ out7, double* __restrict__ err,
+                                                            unsigned* __restrict__ scratch) {
     __shared__ double shd[16];
     __shared__ unsigned long long shl[16][4];
     __shared__ int shm[16][2];
     __shared__ unsigned hist[256 * 33];
     __shared__ int wsum[4];
     __shared__ int sel[2];
+    __shared__ unsigned s_ticket;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the ranks of this thread, f(value, index): 16-byte loads, eight of them in flight (the kernel is ONE workgroup and every pass is
-    // latency-bound: with 4-byte loads unrolled by 8 a pass over 40,000 ranks was five dependent round trips to L2, ~5 us; it is
-    // now two)
-    const bool vec = (((uintptr_t)r) & 15) == 0;
-    const int n4 = vec ? n >> 2 : 0;
-    auto each = [&](auto&& f) {
-#pragma unroll 8
-        for (int i4 = tid; i4 < n4; i4 += 1024) {
-            const int4 q = ((const int4*)r)[i4];
-            f(q.x + base, 4 * i4); f(q.y + base, 4 * i4 + 1); f(q.z + base, 4 * i4 + 2); f(q.w + base, 4 * i4 + 3);
-        }
-        for (int i = 4 * n4 + tid; i < n; i += 1024) f(r[i] + base, i);
-    };
-    // ---- sums: exact integer counters, fp64 for the reciprocal sum
+    const int G = (int)gridDim.x;
+    unsigned* const ghist = scratch + 4;
+    MetricsPartial* const parts = (MetricsPartial*)((char*)scratch + 4096);
+
+    // ---- every block: its share of the sums and of the two histograms (bins replicated 8 times in LDS, pitch 9)
+    for (int i = tid; i < 512 * 9; i += 1024) hist[i] = 0;
+    __syncthreads();
     unsigned long long c1 = 0, c5 = 0, c10 = 0, sum = 0;
     double isum = 0;
     int mx = 0, mn = 0x7fffffff;
-    each([&](int v, int i) {
+    const int rep8 = lane & 7;
+    for (long i = (long)blockIdx.x * 1024 + tid; i < n; i += (long)G * 1024) {
+        const int v = r[i] + base;
         if (ranks_out) ranks_out[i] = v;
         c1 += v <= 1; c5 += v <= 5; c10 += v <= 10;
         sum += (unsigned long long)(long long)v;
@@ -691,47 +705,94 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
         q = q * (2.0 - d * q);
         isum += q;
         mx = max(mx, v); mn = min(mn, v);
-    });
+        const unsigned u = (unsigned)v;
+        if (u < 256u) atomicAdd(&hist[u * 9 + rep8], 1u);
+        atomicAdd(&hist[(256u + min(u >> 8, 255u)) * 9 + rep8], 1u);
+    }
+    auto block_sums = [&]() {                                     // -> thread 0 holds the block's totals
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        c1 += __shfl_xor(c1, o); c5 += __shfl_xor(c5, o); c10 += __shfl_xor(c10, o); sum += __shfl_xor(sum, o);
-        isum += __shfl_xor(isum, o);
-        mx = max(mx, __shfl_xor(mx, o)); mn = min(mn, __shfl_xor(mn, o));
+        for (int o = 32; o >= 1; o >>= 1) {
+            c1 += __shfl_xor(c1, o); c5 += __shfl_xor(c5, o); c10 += __shfl_xor(c10, o); sum += __shfl_xor(sum, o);
+            isum += __shfl_xor(isum, o);
+            mx = max(mx, __shfl_xor(mx, o)); mn = min(mn, __shfl_xor(mn, o));
+        }
+        if (lane == 0) {
+            shl[wave][0] = c1; shl[wave][1] = c5; shl[wave][2] = c10; shl[wave][3] = sum;
+            shd[wave] = isum;
+            shm[wave][0] = mx; shm[wave][1] = mn;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            c1 = c5 = c10 = sum = 0; isum = 0; mx = 0; mn = 0x7fffffff;
+            for (int w = 0; w < 16; ++w) {
+                c1 += shl[w][0]; c5 += shl[w][1]; c10 += shl[w][2]; sum += shl[w][3]; isum += shd[w];
+                mx = max(mx, shm[w][0]); mn = min(mn, shm[w][1]);
+            }
+        }
+    };
+    block_sums();
+    if (tid == 0) {
+        MetricsPartial p{c1, c5, c10, sum, isum, mx, mn, {0, 0, 0, 0}};
+        parts[blockIdx.x] = p;
     }
-    if (lane == 0) {
-        shl[wave][0] = c1; shl[wave][1] = c5; shl[wave][2] = c10; shl[wave][3] = sum;
-        shd[wave] = isum;
-        shm[wave][0] = mx; shm[wave][1] = mn;
+    if (tid < 512) {
+        unsigned t = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += hist[tid * 9 + q];
+        if (t) __hip_atomic_fetch_add(ghist + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __threadfence();
     __syncthreads();
-    mx = 0; mn = 0x7fffffff;
-    for (int w = 0; w < 16; ++w) { mx = max(mx, shm[w][0]); mn = min(mn, shm[w][1]); }
-    mx = __builtin_amdgcn_readfirstlane(mx);
-    mn = __builtin_amdgcn_readfirstlane(mn);
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(scratch, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != (unsigned)(G - 1)) return;
+
+    // ---- the last block
+    __threadfence();
+    {
+        c1 = c5 = c10 = sum = 0; isum = 0; mx = 0; mn = 0x7fffffff;
+        if (tid < G) {
+            const unsigned long long* q = (const unsigned long long*)(parts + tid);
+            unsigned long long w[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w[k] = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c1 = w[0]; c5 = w[1]; c10 = w[2]; sum = w[3];
+            isum = __longlong_as_double((long long)w[4]);
+            mx = (int)(unsigned)w[5]; mn = (int)(unsigned)(w[5] >> 32);
+        }
+        __syncthreads();                                          // (shl / shd / shm are reused)
+        block_sums();
+        if (tid == 0) { shl[0][0] = c1; shl[0][1] = c5; shl[0][2] = c10; shl[0][3] = sum; shd[0] = isum; shm[0][0] = mx; shm[0][1] = mn; }
+    }
+    // the two histograms -> LDS (hist[0..255] = lo, hist[256..511] = hi), scratch cleared for the next launch
+    if (tid < 512) {
+        hist[tid] = __hip_atomic_load(ghist + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ghist + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) __hip_atomic_store(scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    mx = shm[0][0]; mn = shm[0][1];
     if (n > 0 && mn < 1) {                                        // invalid input: report (flag + NaN metrics), do not select
         if (tid < 7) out7[tid] = __builtin_nan("");
         if (tid == 0) err[0] = 1.0;
         return;
     }
-    // ---- k-th smallest (0-based k = n/2)
-    const int k = n / 2;
-    unsigned prefix = 0, mask = 0;
-    int less = 0;                                                 // #{r < smallest value with the current prefix}
-    const int rep = lane & 31;
-    for (int shift = ((32 - __clz(mx | 1) + 7) / 8 - 1) * 8; shift >= 0; shift -= 8) {
-        for (int i = tid; i < 256 * 33; i += 1024) hist[i] = 0;
-        __syncthreads();
-        each([&](int vi, int) {
-            const unsigned v = (unsigned)vi;
-            if ((v & mask) == prefix) atomicAdd(&hist[((v >> shift) & 255u) * 33 + rep], 1u);
-        });
-        __syncthreads();
-        // threads 0..255: bin totals, inclusive scan over the 256 bins, the owner of k publishes its digit
-        int own = 0, inc = 0;
+    const int k = n / 2;                                          // k-th smallest, 0-based
+    // the ranks again, one workgroup: 16-byte loads, eight of them in flight (every pass is latency-bound)
+    const bool vec = (((uintptr_t)r) & 15) == 0;
+    const int n4 = vec ? n >> 2 : 0;
+    auto each = [&](auto&& f) {
+#pragma unroll 8
+        for (int i4 = tid; i4 < n4; i4 += 1024) {
+            const int4 q = ((const int4*)r)[i4];
+            f(q.x + base); f(q.y + base); f(q.z + base); f(q.w + base);
+        }
+        for (int i = 4 * n4 + tid; i < n; i += 1024) f(r[i] + base);
+    };
+    // owner of position k among 256 bins held by threads 0..255 (`own` each): sel[0] = bin, sel[1] = #{elements in lower bins} + less
+    auto select_bin = [&](int own, int less) {
+        int inc = own;
         if (tid < 256) {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) own += (int)hist[tid * 33 + q];
-            inc = own;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int t = __shfl_up(inc, o);
@@ -746,40 +807,75 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
             if (before <= k && k < before + own) { sel[0] = tid; sel[1] = before; }     // exactly one thread
         }
         __syncthreads();
+    };
+    unsigned prefix = 0, mask = 0;
+    int less = 0;                                                 // #{r < smallest value with the current prefix}
+    int shift;
+    int below = 0;                                                // largest rank below the median's value, when known from lo[]
+    bool below_known = false;
+    const int in_lo = (int)hist[256];                             // hi[0] = #{v < 256}
+    if (k < in_lo) {
+        select_bin(tid < 256 ? (int)hist[tid] : 0, 0);
+        prefix = (unsigned)sel[0]; less = sel[1];
+        mask = 0xffffffffu;
+        shift = -8;
+        for (int b = (int)prefix - 1; b >= 1; --b)                // (uniform: every thread walks the same LDS words)
+            if (hist[b]) { below = b; break; }
+        below_known = true;
+    } else {
+        select_bin(tid < 256 ? (int)hist[256 + tid] : 0, 0);
+        if (sel[0] < 255) { prefix = (unsigned)sel[0] << 8; less = sel[1]; mask = 0xffffff00u; shift = 0; }
+        else shift = ((32 - __clz(mx | 1) + 7) / 8 - 1) * 8;      // ranks from 65,280 up: the general select
+    }
+    const int rep = lane & 31;
+    for (; shift >= 0; shift -= 8) {
+        __syncthreads();
+        for (int i = tid; i < 256 * 33; i += 1024) hist[i] = 0;
+        __syncthreads();
+        each([&](int vi) {
+            const unsigned v = (unsigned)vi;
+            if ((v & mask) == prefix) atomicAdd(&hist[((v >> shift) & 255u) * 33 + rep], 1u);
+        });
+        __syncthreads();
+        int own = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) own += (int)hist[tid * 33 + q];
+        }
+        select_bin(own, less);
         prefix |= (unsigned)sel[0] << shift;
         mask |= 255u << shift;
         less = sel[1];
     }
     const int med_lo = (int)prefix;
     double med = med_lo;
-    if (n > 0 && (n & 1) == 0) {
-        // sorted[k-1]: equals sorted[k] unless exactly k elements are smaller, then it is the largest of those
-        int below = 0;
-        each([&](int v, int) {
-            if (v < med_lo) below = max(below, v);
-        });
+    if (n > 0 && (n & 1) == 0 && less >= k) {
+        // sorted[k-1] equals sorted[k] unless exactly k elements are smaller: then it is the largest of those
+        if (!below_known) {
+            each([&](int v) {
+                if (v < med_lo) below = max(below, v);
+            });
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) below = max(below, __shfl_xor(below, o));
-        __syncthreads();
-        if (lane == 0) shm[wave][0] = below;
-        __syncthreads();
-        below = 0;
-        for (int w = 0; w < 16; ++w) below = max(below, shm[w][0]);
-        const double prev = (less >= k) ? (double)below : (double)med_lo;
-        med = 0.5 * (med + prev);
+            for (int o = 32; o >= 1; o >>= 1) below = max(below, __shfl_xor(below, o));
+            __syncthreads();
+            if (lane == 0) shm[wave][0] = below;
+            __syncthreads();
+            below = 0;
+            for (int w = 0; w < 16; ++w) below = max(below, shm[w][0]);
+        }
+        med = 0.5 * (med + (double)below);
     }
     if (tid == 0) {
-        c1 = c5 = c10 = sum = 0; isum = 0;
-        for (int w = 0; w < 16; ++w) { c1 += shl[w][0]; c5 += shl[w][1]; c10 += shl[w][2]; sum += shl[w][3]; isum += shd[w]; }
         const double dn = (double)n;
-        out7[0] = 100.0 * ((double)c1 / dn); out7[1] = 100.0 * ((double)c5 / dn); out7[2] = 100.0 * ((double)c10 / dn);
-        out7[3] = floor(med); out7[4] = (double)sum / dn; out7[5] = isum / dn; out7[6] = isum / dn;
+        out7[0] = 100.0 * ((double)shl[0][0] / dn); out7[1] = 100.0 * ((double)shl[0][1] / dn); out7[2] = 100.0 * ((double)shl[0][2] / dn);
+        out7[3] = floor(med); out7[4] = (double)shl[0][3] / dn; out7[5] = shd[0] / dn; out7[6] = shd[0] / dn;
         err[0] = 0.0;
     }
 }
 
-hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, hipStream_t st) {
-    hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(1024), 0, st, r, n, base, ranks_out, out7, err);
+hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, unsigned* scratch, hipStream_t st) {
+    const int G = std::min(MS_GMAX, std::max(1, (n + 1023) / 1024));
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)G), dim3(1024), 0, st, r, n, base, ranks_out, out7, err, scratch);
     return hipGetLastError();
 }
 

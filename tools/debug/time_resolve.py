@@ -1,41 +1,31 @@
-"""Launch time of laff_rank_resolve / laff_rank_prepare at C4 (bench workload's embeddings): python tools/debug/time_resolve.py [fp16]"""
-import os
-import sys
-
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import torch  # noqa: E402
-
-from laff_amd import ops, retrieval, synth  # noqa: E402
-
-prec = sys.argv[1] if len(sys.argv) > 1 else 'fp16'
-dev = torch.device('cuda')
-Nt, Nv, K = 40000, 10000, 512
-m = synth.build_model(1, 512, dev, seed=1237)
-vis, txt, gt, _ = synth.make_features(Nt, Nv, dev, seed=1237)
+"""laff_rank_resolve alone on a synthetic workload's own list (default C4): python tools/debug/time_resolve.py [workload]"""
+import sys, torch
+sys.path.insert(0, '.')
+from laff_amd import ops, synth, retrieval
+wl = sys.argv[1] if len(sys.argv) > 1 else 'c4_40kx10k'
+dev = torch.device('cuda:0')
+Nt, Nv, heads, d, frames = synth.WORKLOADS[wl]
+spec = synth.SPECS.get(wl)
+model = synth.build_model(heads, d, dev, frames=frames, seed=1237, spec=spec)
+vis, txt, gt, lens = synth.make_features(Nt, Nv, dev, frames=frames, seed=1237, spec=spec)
 with torch.no_grad():
-    v, t = retrieval.embed(m, vis, txt)
-t, v = t.reshape(Nt, 1, K).contiguous(), v.reshape(Nv, 1, K).contiguous()
-T, V = ops.pack_rows(t, True, 1e-13, prec), ops.pack_rows(v, True, 1e-13, prec)
-
-
-def timed(fn, n=50):
-    for _ in range(5):
-        fn()
+    ve, te = retrieval.embed(model, vis, txt)
+T, V = ops.pack_rows(te, True, 1e-13, 'fp16'), ops.pack_rows(ve, True, 1e-13, 'fp16')
+def timeit(fn, n=50):
+    for _ in range(3): fn()
     torch.cuda.synchronize()
-    best = []
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        best.append(e0.elapsed_time(e1) / n * 1e3)
-    return sorted(best)[2]
-
-
-st = ops.rank_prepare(t, v, T, V, gt)
-for scores in (False, True):
-    S = ops.sim_gemm_banded(st, scores)
-    print('%s scores=%s: %d pairs listed; rank_resolve %.1f us, rank_prepare %.1f us' % (
-        prec, scores, st.listed_pairs()[0], timed(lambda: ops.rank_resolve(st, S)), timed(lambda: ops.rank_prepare(t, v, T, V, gt))))
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+S = ops.alloc_scores(Nt, Nv, dev)
+st = ops.rank_prepare(te, ve, T, V, gt)
+st.pairs[:4].zero_()
+ops.sim_gemm_banded(st, out=S)
+print(wl, 'pairs', st.listed_pairs(), 'header', st.pairs[:4].tolist())
+c0 = st.count.clone()
+ops.rank_resolve(st, S)
+print('counts changed by resolve on %d rows' % int((st.count != c0).sum()))
+print('resolve        %.4f ms' % timeit(lambda: ops.rank_resolve(st, S)))
+print('resolve no S   %.4f ms' % timeit(lambda: ops.rank_resolve(st, None)))
