@@ -325,6 +325,36 @@ def test_rank_metrics_device_vs_numpy(n, hi):
         ops.rank_metrics(dev(np.array([1, 0, 3], np.int32), torch.int32))
 
 
+def _metrics_numpy(r):
+    ranks = r.astype(np.float64)
+    return (100.0 * np.mean(ranks <= 1), 100.0 * np.mean(ranks <= 5), 100.0 * np.mean(ranks <= 10), np.floor(np.median(ranks)),
+            ranks.mean(), (1.0 / ranks).mean(), (1.0 / ranks).mean())
+
+
+def test_rank_metrics_median_cases_of_the_histogram_paths():
+    """The last block of the metrics launch takes the median out of the lo[] histogram (ranks < 256), out of hi[] + one pass, or out of
+    the general select; even n needs sorted[k - 1] too, which may sit in another bin / byte / path.  A failed launch (rank < 1) must
+    leave the scratch clean for the next one; n beyond 256 x 1024 makes every thread take several ranks."""
+    from laff_amd import ops
+    g = rnd(4242)
+    cases = [np.array([3, 3, 7, 9], np.int32),                       # sorted[k-1] = 3, sorted[k] = 7: both in lo[]
+             np.array([1, 1, 300, 400], np.int32),                   # below in lo[], median beyond it
+             np.array([255, 256], np.int32), np.array([256, 255, 255, 256], np.int32),
+             np.array([65279, 65280], np.int32), np.array([70000, 65279, 1, 65281], np.int32),
+             np.array([511, 512, 512, 511], np.int32), np.array([5], np.int32), np.array([2 ** 31 - 1, 1], np.int32),
+             g.integers(1, 200, 40000).astype(np.int32), g.integers(1, 200, 40001).astype(np.int32),
+             g.integers(250, 262, 5000).astype(np.int32), g.integers(65270, 65290, 5000).astype(np.int32),
+             g.integers(1, 50000, 300000).astype(np.int32), g.integers(1, 100, 1 << 19).astype(np.int32)]
+    for r in cases:
+        got = ops.rank_metrics(dev(r, torch.int32))
+        np.testing.assert_allclose(got, _metrics_numpy(r), rtol=1e-13, atol=0, err_msg=str(r[:8]))
+        with pytest.raises(RuntimeError):
+            bad = r.copy(); bad[len(bad) // 2] = 0
+            ops.rank_metrics(dev(bad, torch.int32))
+        got2 = ops.rank_metrics(dev(r, torch.int32))
+        assert tuple(got2) == tuple(got)                           # same bits: fixed reduction order, clean scratch
+
+
 @pytest.mark.parametrize('N,Dk,D', [(1, 4, 4), (33, 96, 512), (130, 1030, 260), (300, 512, 512), (70, 77, 130), (5, 3981, 200)])
 def test_fc_split_fp16x3_vs_fp64(N, Dk, D):
     """FC on the fp16 pipe with the exact hi/lo split: same tolerance as the fp32-MFMA path, incl. huge / tiny rows."""
