@@ -81,6 +81,10 @@ template <int IMM>
 __device__ __forceinline__ void lds_write128(unsigned addr, const f32x4& v) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(IMM) : "memory");
 }
+template <int IMM>
+__device__ __forceinline__ void lds_read128_a(u32x4& d, unsigned addr) {        // ... into the accumulator half of the register file
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(addr), "n"(IMM));
+}
 template <int N>
 __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N>
@@ -99,6 +103,12 @@ __device__ __forceinline__ void dma_piece(unsigned lane16x, u32x4 rsrc, unsigned
     asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                  :: "v"(voff), "s"(rsrc), "s"(m0base), "n"(P * 1024)
                  : "memory", "scc");          // s_add writes SCC: undeclared, hipcc put one of these between an s_add_u32 / s_addc_u32 pair
+}
+// one 1 KiB piece of the strip staging: lane L's 16 bytes at descriptor offset voff + soff -> LDS (m0base + LDSOFF) + 16 L
+template <int LDSOFF>
+__device__ __forceinline__ void stage_piece(unsigned voff, u32x4 rsrc, unsigned soff, unsigned m0base) {
+    asm volatile("s_add_i32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(m0base), "n"(LDSOFF) : "memory", "scc");
 }
 // raw buffer descriptor of `bytes_total` bytes at `base`, re-based by `off` bytes (empty when off is beyond the end)
 __device__ __forceinline__ u32x4 rebased_rsrc(unsigned long long base, unsigned long long bytes_total, unsigned long long off) {
@@ -442,14 +452,6 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
 #endif
         STAMP(tb);
 
-        // ---- the strip -> registers (once per segment) ---------------------------------------------------------------------
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const __attribute__((address_space(1))) char* src =
-                (const __attribute__((address_space(1))) char*)pT + (size_t)std::min(row_w + rb * 32 + l31, nR - 1) * KBYTES + 16 * hh;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) B[rb][j] = *(const gu32x4*)(src + 32 * j);
-        }
         // per-row inputs of the banded count
         float sgf[2] = {0, 0}, brow[2] = {0, 0};
         int gtc[2] = {-1, -1};
@@ -464,6 +466,54 @@ __global__ __launch_bounds__(256, 1) void sim_strip_kernel(const StripArgs a) {
                 gtc[rb] = r < nR ? a.gt_col[rc] - col0 : -1;
             }
         }
+        // ---- the strip -> registers (once per segment): eight K-eighth rounds (64 rows x 128 bytes: one line of every row) by LDS-DMA
+        // through three 8 KiB buffers of this wave in the idle ring, then 8 ds_read_b128 per round into the accumulator file.  (As 64
+        // direct 16-byte loads per lane at 1 KiB stride -- the fragment layout -- every load instruction touched 32 lines for 32 bytes
+        // each: bound by the CU's address path, ~21k cycles per segment.)  Instruction t of a round: rows 8 t + (lane >> 3), LDS chunk
+        // lane & 7 of the row <- its logical chunk (lane & 7) ^ (row & 7) (the swizzle on the source side, LDS-DMA writes lane-linear).
+        {
+            const int rows_w = std::min(64, nR - row_w);                         // rows of this wave inside the matrix (may be <= 0)
+            // rows beyond the matrix read as zeros (the range check of this descriptor covers VGPR + scalar offset: measured -- with
+            // 896 bytes held back for the scalar round offset the last row lost rounds 1..7)
+            const u32x4 rsrcT = rebased_rsrc(pT + (unsigned long long)(rows_w > 0 ? row_w : 0) * KBYTES,
+                                             rows_w > 0 ? (unsigned long long)rows_w * KBYTES : 0ull, 0ull);
+            unsigned ln = (unsigned)lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned sv0 = (ln >> 3) * (unsigned)KBYTES + (((ln & 7u) ^ ((ln >> 3) & 7u)) << 4);
+            const unsigned stg = pin_s(lds0 + (unsigned)wave * (3u * 8192u));
+            unsigned xr[4];                                                       // read-back: row l31 (+ 32 rb), chunk (2 q + hh) ^ (row & 7)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[q] = stg + (ln & 31u) * 128u + ((((unsigned)(2 * q) + (ln >> 5)) ^ (ln & 7u)) << 4);
+            auto issue_round = [&](auto EC) {
+                constexpr int e = decltype(EC)::value, buf = e % 3;
+                static_for<0, 8>([&](auto TC) {
+                    constexpr int t = decltype(TC)::value;
+                    stage_piece<buf * 8192 + t * 1024>(sv0 + (unsigned)(t * 8 * KBYTES), rsrcT, (unsigned)(e * 128), stg);
+                });
+            };
+            auto read_round = [&](auto EC) {
+                constexpr int e = decltype(EC)::value, buf = e % 3;
+                static_for<0, 8>([&](auto IC) {
+                    constexpr int rb = decltype(IC)::value >> 2, q = decltype(IC)::value & 3;
+                    lds_read128_a<buf * 8192 + rb * 4096>(B[rb][4 * e + q], xr[q]);
+                });
+                wait_lgkm<0>();                                                   // (the buffer is refilled next)
+            };
+            using E0 = std::integral_constant<int, 0>; using E1 = std::integral_constant<int, 1>; using E2 = std::integral_constant<int, 2>;
+            using E3 = std::integral_constant<int, 3>; using E4 = std::integral_constant<int, 4>; using E5 = std::integral_constant<int, 5>;
+            using E6 = std::integral_constant<int, 6>; using E7 = std::integral_constant<int, 7>;
+            issue_round(E0{}); issue_round(E1{}); issue_round(E2{});
+            wait_vm<16>(); read_round(E0{}); issue_round(E3{});
+            wait_vm<16>(); read_round(E1{}); issue_round(E4{});
+            wait_vm<16>(); read_round(E2{}); issue_round(E5{});
+            wait_vm<16>(); read_round(E3{}); issue_round(E6{});
+            wait_vm<16>(); read_round(E4{}); issue_round(E7{});
+            wait_vm<16>(); read_round(E5{});
+            wait_vm<8>(); read_round(E6{});
+            wait_vm<0>(); read_round(E7{});
+        }
+        __builtin_amdgcn_s_barrier();            // every wave has emptied its staging buffers: the ring prologue may fill the slots
+        asm volatile("" ::: "memory");
         // thresholds of the block whose epilogue comes next, [rb], in accumulator units: written behind the block barrier of the
         // block's own K loop, read by its epilogue in the next body (whose stream stays in front of ITS barrier) or by the drain.
         // Initial value: nothing counted, nothing listed -- the first body's epilogue runs on an all-zero accumulator set.
