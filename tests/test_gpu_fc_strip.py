@@ -55,6 +55,24 @@ def test_fc_strip_vs_fp64(N, D, act):
     assert float(np.max(np.abs((y - y32).cpu().numpy()) / scale)) <= 2e-5
 
 
+@pytest.mark.parametrize('N,D', [(40000, 64), (40000, 96), (20000, 128), (33000, 160), (9000, 32), (70000, 32), (12800, 1024)])
+def test_fc_strip_segment_shapes(N, D):
+    """A workgroup's range is cut into segments (the blocks of one strip).  Segments of 1, 2, 3, ... blocks with and without a successor
+    take different code: the plain loop may be empty, the last two blocks are the copies whose bodies fetch the next strip's first rounds,
+    one-block segments fetch nothing ahead.  Narrow outputs over many rows produce all of them."""
+    from laff_amd import ops
+    g = rnd(N + D)
+    x = g.normal(0, 1, (N, 512)).astype(np.float32)
+    W, b, sc, sh = _layer(g, D)
+    sw = ops.fc_strip_pack(dev(W), dev(b), dev(sc), dev(sh), 'tanh')
+    y = ops.fc_act_bn_strip_grouped([dict(x=dev(x), strip=sw)])[0]
+    y32 = ops.fc_act_bn(dev(x), dev(W), dev(b), dev(sc), dev(sh), 'tanh')
+    assert float((y - y32).abs().max()) <= 2e-5
+    rows = np.r_[0:300, N - 300:N]
+    ref, _ = _ref64(x[rows], W, b, sc, sh, 'tanh')
+    assert float(np.max(np.abs(y.cpu().numpy()[rows] - ref))) <= 2e-5
+
+
 @pytest.mark.parametrize('bias,bn', [(False, False), (True, False), (False, True)])
 def test_fc_strip_optional_stages_and_padded_rows(bias, bn):
     """bias / BatchNorm absent; input and output rows with a pitch (views of wider buffers): nothing outside [N, D] is written."""
