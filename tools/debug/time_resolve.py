@@ -29,3 +29,23 @@ ops.rank_resolve(st, S)
 print('counts changed by resolve on %d rows' % int((st.count != c0).sum()))
 print('resolve        %.4f ms' % timeit(lambda: ops.rank_resolve(st, S)))
 print('resolve no S   %.4f ms' % timeit(lambda: ops.rank_resolve(st, None)))
+# the two-kernel form: export the listed pairs as one plain bucket (laff_rank_export_pairs, world = 1), then laff_rank_resolve on it
+st = ops.rank_prepare(te, ve, T, V, gt)
+st.pairs[:4].zero_()
+ops.sim_gemm_banded(st, out=S)
+bounds = torch.tensor([0, Nt], dtype=torch.int32, device=dev)
+cap = 1 << 17
+def two():
+    out, fill = ops.rank_export_pairs(st, S, bounds, 0, cap)
+    lst = torch.empty(4 + 2 * cap, dtype=torch.int32, device=dev)
+    lst[:4] = torch.tensor([0, 0, cap, 4], dtype=torch.int32, device=dev)
+    lst[4:] = out.reshape(-1)
+    return ops.rank_resolve_list(te, ve, st.s_gt64, st.count, lst), fill
+c, fill = two(); torch.cuda.synchronize()
+print('export fill', fill.tolist())
+out, fill = ops.rank_export_pairs(st, S, bounds, 0, cap)
+lst = torch.empty(4 + 2 * cap, dtype=torch.int32, device=dev)
+lst[:4] = torch.tensor([0, 0, cap, 4], dtype=torch.int32, device=dev)
+lst[4:] = out.reshape(-1)
+print('export alone        %.4f ms' % timeit(lambda: ops.rank_export_pairs(st, S, bounds, 0, cap)))
+print('resolve_list alone  %.4f ms' % timeit(lambda: ops.rank_resolve_list(te, ve, st.s_gt64, st.count, lst)))
