@@ -71,5 +71,18 @@ int main() {
     run<4, 2, 4, true>("sub+alignbit pairs (reads acc)", d, sink);
     run<2, 2, 4, true>("sub+alignbit pairs (reads acc)", d, sink);
     run<4, 3, 4, true>("sub+alignbit pairs (reads acc)", d, sink);
+    // one accumulator (every MFMA depends on the one before it: fc_strip's chain of three per sub-step)
+    run<1, 0, 0, true>("bare, ONE accumulator", d, sink);
+    run<1, 1, 3, true>("s_nop 0, one accumulator", d, sink);
+    run<1, 2, 3, true>("s_nop 0, one accumulator", d, sink);
+    run<1, 1, 0, true>("indep VALU, one accumulator", d, sink);
+    run<1, 2, 0, true>("indep VALU, one accumulator", d, sink);
+    run<1, 3, 0, true>("indep VALU, one accumulator", d, sink);
+    run<1, 4, 0, true>("indep VALU, one accumulator", d, sink);
+    run<1, 6, 0, true>("indep VALU, one accumulator", d, sink);
+    run<1, 8, 0, true>("indep VALU, one accumulator", d, sink);
+    run<2, 1, 3, true>("s_nop 0", d, sink);
+    run<2, 6, 0, true>("indep VALU", d, sink);
+    run<2, 8, 0, true>("indep VALU", d, sink);
     return 0;
 }
