@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 18
+#define LAFF_ABI_VERSION 19
 
 enum {
     LAFF_OK = 0,
@@ -253,6 +253,12 @@ int laff_frame_fuse(laff_ctx* ctx, const float* frames, const int* lens, int B, 
 int laff_frame_fuse_grouped(laff_ctx* ctx, int count, const float* const* frames, const int* lens, int B, int Fmax, int d,
                             const float* const* w, const float* const* b, const float* const* gw, unsigned flags,
                             float* const* V);
+/* the same, fed with the reference's mask_tensor (model/model.py:2156-2160: fp32 (B, ldm >= Fmax), ones for the frames a video has,
+ * then zeros) instead of lens: lens[b] = round(sum_f mask[b][f]) is taken inside the launch -- `mask.sum(dim=1).int()` as two
+ * framework launches in front of this one was 15 us of a 0.47 ms pass (C3) */
+int laff_frame_fuse_grouped_mask(laff_ctx* ctx, int count, const float* const* frames, const float* mask, int ldm, int B, int Fmax,
+                                 int d, const float* const* w, const float* const* b, const float* const* gw, unsigned flags,
+                                 float* const* V);
 
 /* ---- a8: loss.l2norm (loss.py:8-13) + operand packing for the similarity GEMM ---------------------------
  * For each (n,h): y = x / (||x||_2 + eps + 1e-14) if normalize, then y * prescale, converted to `precision`.

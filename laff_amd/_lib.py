@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get('LAFF_HIP_LIB') or os.path.join(_HERE, 'lib', 'liblaff
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class Plane(C.Structure):
@@ -68,6 +68,8 @@ SIGNATURES = {
     'laff_fc_act_bn_strip_grouped': (C.c_int, [_P, C.POINTER(FcStripProblem), _I]),
     'laff_frame_fuse_grouped': (C.c_int, [_P, _I, C.POINTER(C.c_void_p), _P, _I, _I, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.c_uint, C.POINTER(C.c_void_p)]),
+    'laff_frame_fuse_grouped_mask': (C.c_int, [_P, _I, C.POINTER(C.c_void_p), _P, _I, _I, _I, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_void_p), C.c_uint, C.POINTER(C.c_void_p)]),
     'laff_split_rows_bytes': (C.c_int, [_I, _I, C.POINTER(C.c_size_t)]),
     'laff_split_rows': (C.c_int, [_P, _P, _I, _I, _I, _P, _P]),
     'laff_split_rows_grouped': (C.c_int, [_P, _I, C.POINTER(C.c_void_p), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I),

@@ -641,8 +641,8 @@ int laff_plane_row_norms(laff_ctx* ctx, const laff_plane* planes, int L, int N, 
     return LAFF_OK;
 }
 
-int laff_frame_fuse_grouped(laff_ctx* ctx, int count, const float* const* frames, const int* lens, int B, int Fmax, int d,
-                            const float* const* w, const float* const* b, const float* const* gw, unsigned flags, float* const* V) {
+static int frame_fuse_grouped(laff_ctx* ctx, int count, const float* const* frames, const int* lens, const float* mask, int ldm, int B, int Fmax,
+                              int d, const float* const* w, const float* const* b, const float* const* gw, unsigned flags, float* const* V) {
     CHECK_CTX(ctx);
     if (B == 0 || count == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */
     if (count < 0 || !frames || !w || !b || !V) return fail(LAFF_E_ARG, "laff_frame_fuse: null frames/w/b/V");
@@ -659,11 +659,22 @@ int laff_frame_fuse_grouped(laff_ctx* ctx, int count, const float* const* frames
             if (!frames[k] || !w[k] || !b[k] || !V[k]) return fail(LAFF_E_ARG, "laff_frame_fuse: feature %d has a null pointer", k);
             if ((flags & LAFF_ATT_WITH_AVE) && (!gw || !gw[k])) return fail(LAFF_E_ARG, "laff_frame_fuse: WITH_AVE needs gw");
             if (!aligned16(frames[k]) || !aligned16(w[k]) || !aligned16(V[k])) return fail(LAFF_E_ALIGN, "laff_frame_fuse: 16-byte alignment");
-            grp.f[i] = laff::FrameArgs{frames[k], lens, B, Fmax, d, w[k], b[k], gw ? gw[k] : nullptr, flags, V[k]};
+            grp.f[i] = laff::FrameArgs{frames[k], lens, B, Fmax, d, w[k], b[k], gw ? gw[k] : nullptr, flags, V[k], mask, ldm};
         }
         HIP_TRY(laff::launch_frame_fuse(grp, ctx->stream));
     }
     return LAFF_OK;
+}
+
+int laff_frame_fuse_grouped(laff_ctx* ctx, int count, const float* const* frames, const int* lens, int B, int Fmax, int d,
+                            const float* const* w, const float* const* b, const float* const* gw, unsigned flags, float* const* V) {
+    return frame_fuse_grouped(ctx, count, frames, lens, nullptr, 0, B, Fmax, d, w, b, gw, flags, V);
+}
+
+int laff_frame_fuse_grouped_mask(laff_ctx* ctx, int count, const float* const* frames, const float* mask, int ldm, int B, int Fmax, int d,
+                                 const float* const* w, const float* const* b, const float* const* gw, unsigned flags, float* const* V) {
+    if (B > 0 && count > 0 && (!mask || ldm < Fmax)) return fail(LAFF_E_ARG, "laff_frame_fuse_grouped_mask: mask must be (B, ldm >= Fmax)");
+    return frame_fuse_grouped(ctx, count, frames, nullptr, mask, ldm, B, Fmax, d, w, b, gw, flags, V);
 }
 
 int laff_frame_fuse(laff_ctx* ctx, const float* frames, const int* lens, int B, int Fmax, int d, const float* w,

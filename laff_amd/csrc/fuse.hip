@@ -525,7 +525,15 @@ __global__ __launch_bounds__(256) void frame_fuse_kernel(FrameGroup grp) {
     const FrameArgs& a = grp.f[feat];
     const int bidx = (int)blockIdx.x - feat * a.B;
     const int d = a.d, Fmax = a.Fmax;
-    const int len = a.lens ? min(max(a.lens[bidx], 0), Fmax) : Fmax;
+    int len = Fmax;
+    if (a.mask) {
+        // lens = mask_tensor.sum(dim = 1) (model/model.py:2156-2160 builds the row as ones followed by zeros): every wave sums the row
+        float t = 0.f;
+        for (int f = lane; f < Fmax; f += 64) t += a.mask[(long)bidx * a.ldm + f];
+        len = min(max((int)(wave_sum(t) + 0.5f), 0), Fmax);
+    } else if (a.lens) {
+        len = min(max(a.lens[bidx], 0), Fmax);
+    }
     const float* base = a.frames + (long)bidx * Fmax * d;
     const bool mul = a.flags & LAFF_ATT_MUL;
     const bool with_ave = a.flags & LAFF_ATT_WITH_AVE;

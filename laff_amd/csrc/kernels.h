@@ -173,6 +173,8 @@ struct FrameArgs {
     const float* gw;
     unsigned flags;
     float* V;             // [B, d]
+    const float* mask;    // [B, ldm] or null: the reference's mask_tensor (1.0 per valid frame, a prefix of the row); replaces lens
+    int ldm;
 };
 struct FrameGroup {       // up to 8 frame features of the same shape in ONE launch: block -> (feature, video)
     int count;

@@ -592,13 +592,17 @@ class VisMutiTransformNetPlusFrameFeat(nn.Module):
         if len(names) > 1 and len(shapes) == 1 and not self.opt.vis_frame_addFC:
             # every frame feature of the tower in ONE launch (same shape, same attention type, shared lens)
             frames = [vis_frame_feat_dict_input[k].contiguous() for k in names]
-            lens = vis_frame_feat_dict_input['mask_tensor'].to(device=frames[0].device).sum(dim=1).to(torch.int32).contiguous()
+            mask = vis_frame_feat_dict_input['mask_tensor'].to(device=frames[0].device)
+            lens = None
+            if mask.dtype != torch.float32 or mask.dim() != 2 or mask.stride(1) != 1:
+                lens, mask = mask.sum(dim=1).to(torch.int32).contiguous(), None      # (any other mask type: the framework sums it)
             atts = [self.frame_attention[k][-1] for k in names]
             params = []
             for att in atts:
                 w, b, gw = att._params()
                 params.append((w.reshape(-1), b, gw))
-            vecs = ops.frame_fuse_grouped(frames, lens, params, ops.attention_flags(atts[0].with_ave, atts[0].mul))
+            # (a float mask goes to the launch as it is: the launch takes lens = mask.sum(dim=1) itself)
+            vecs = ops.frame_fuse_grouped(frames, lens, params, ops.attention_flags(atts[0].with_ave, atts[0].mul), mask=mask)
             for k, v in zip(names, vecs):
                 vis_input[k] = v
         else:

@@ -484,8 +484,9 @@ def frame_fuse(frames, lens, w, b, gw, flags):
     return V
 
 
-def frame_fuse_grouped(frames_list, lens, params, flags):
-    """frame_fuse for several frame features of the same shape in one launch.  frames_list: [(B, Fmax, d)], params: [(w, b, gw)]."""
+def frame_fuse_grouped(frames_list, lens, params, flags, mask=None):
+    """frame_fuse for several frame features of the same shape in one launch.  frames_list: [(B, Fmax, d)], params: [(w, b, gw)].
+    mask (fp32 (B, >= Fmax) device tensor, rows of ones then zeros: the reference's mask_tensor) replaces lens: the launch sums it."""
     n = len(frames_list)
     B, Fmax, d = frames_list[0].shape
     F, W, Bb, G, Vv = ((C.c_void_p * n)() for _ in range(5))
@@ -498,9 +499,15 @@ def frame_fuse_grouped(frames_list, lens, params, flags):
         F[i], W[i], Bb[i], G[i], Vv[i] = fr.data_ptr(), _dev(w, 'w').data_ptr(), _dev(b, 'b').data_ptr(), _ptr(gw), V.data_ptr()
         outs.append(V)
         keep.append((fr, w, b, gw))
+    lib, h = _context(frames_list[0].device)
+    if mask is not None:
+        _dev(mask, 'mask')
+        if mask.dim() != 2 or mask.shape[0] != B or mask.shape[1] < Fmax or mask.stride(1) != 1:
+            raise ValueError('mask must be (%d, >= %d) with unit column stride' % (B, Fmax))
+        _call('frame_fuse', lib.laff_frame_fuse_grouped_mask, h, n, F, _ptr(mask), mask.stride(0), B, Fmax, d, W, Bb, G, flags, Vv)
+        return outs
     if lens is not None:
         _dev(lens, 'lens', torch.int32)
-    lib, h = _context(frames_list[0].device)
     _call('frame_fuse', lib.laff_frame_fuse_grouped, h, n, F, _ptr(lens), B, Fmax, d, W, Bb, G, flags, Vv)
     return outs
 

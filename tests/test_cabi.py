@@ -16,7 +16,7 @@ def declared_symbols():
 
 def test_header_declares_the_expected_surface():
     syms = declared_symbols()
-    for s in ('laff_ctx_create', 'laff_fc_act_bn', 'laff_fuse', 'laff_frame_fuse', 'laff_pack_rows', 'laff_sim_gemm',
+    for s in ('laff_ctx_create', 'laff_fc_act_bn', 'laff_fuse', 'laff_frame_fuse', 'laff_frame_fuse_grouped_mask', 'laff_pack_rows', 'laff_sim_gemm',
               'laff_rank_count', 'laff_v2t_count', 'laff_v2t_count_exact', 'laff_rank_metrics', 'laff_last_error'):
         assert s in syms
 

@@ -694,6 +694,23 @@ def test_frame_fuse_grouped_equals_per_feature_launches():
         grouped = ops.frame_fuse_grouped(frames, ld, params, flags)
         for f, (w, b, gw), v in zip(frames, params, grouped):
             assert torch.equal(v, ops.frame_fuse(f, ld, w, b, gw, flags))
+        # the reference's mask_tensor instead of lens (summed inside the launch), also as a view into a wider buffer, Fmax beyond a wave
+        mask = (torch.arange(Fmax, device='cuda')[None, :] < ld[:, None]).to(torch.float32)
+        wide = torch.zeros((B, Fmax + 7), device='cuda')
+        wide[:, :Fmax] = mask
+        for m in (mask, wide[:, :Fmax]):
+            for v, w in zip(grouped, ops.frame_fuse_grouped(frames, None, params, flags, mask=m)):
+                assert torch.equal(v, w)
+    B2, F2, d2 = 5, 150, 64
+    l2 = np.array([0, 1, 64, 65, 150], np.int32)
+    f2 = np.zeros((B2, F2, d2), np.float32)
+    for i in range(B2):
+        f2[i, :l2[i]] = g.normal(0, 1, (l2[i], d2))
+    fr2, pr2 = [dev(f2)], [params[0][:0] + (dev(g.normal(0, 0.2, d2).astype(np.float32)), params[0][1], params[0][2])]
+    flags = ops.attention_flags(True, False)
+    a = ops.frame_fuse_grouped(fr2, dev(l2, torch.int32), pr2, flags)[0]
+    m2 = (torch.arange(F2, device='cuda')[None, :] < dev(l2, torch.int32)[:, None]).to(torch.float32)
+    assert torch.equal(a, ops.frame_fuse_grouped(fr2, None, pr2, flags, mask=m2)[0])
 
 
 @pytest.mark.parametrize('H,d,act', [(8, 512, 'tanh'), (1, 64, None), (2, 256, 'relu'), (4, 128, 'sigmoid')])
