@@ -40,6 +40,11 @@ __device__ __forceinline__ double exact_cos_with(LoadT&& load_t, const float* __
             tt += (double)(a.x + a.y + a.z + a.w); vv += (double)(b.x + b.y + b.z + b.w); tv += 1.0;
             continue;
 #endif
+#ifdef LAFF_EXACT_TVONLY                  /* timing only: what stored row norms would leave of the chains */
+            { const double ax_ = a.x, ay_ = a.y, az_ = a.z, aw_ = a.w, bx_ = b.x, by_ = b.y, bz_ = b.z, bw_ = b.w;
+              tv = fma(ax_, bx_, tv); tv = fma(ay_, by_, tv); tv = fma(az_, bz_, tv); tv = fma(aw_, bw_, tv); tt = 1.0; vv = 1.0; }
+            continue;
+#endif
             const double ax = a.x, ay = a.y, az = a.z, aw = a.w, bx = b.x, by = b.y, bz = b.z, bw = b.w;
             tt = fma(ax, ax, tt); tt = fma(ay, ay, tt); tt = fma(az, az, tt); tt = fma(aw, aw, tt);
             vv = fma(bx, bx, vv); vv = fma(by, by, vv); vv = fma(bz, bz, vv); vv = fma(bw, bw, vv);
