@@ -934,10 +934,10 @@ bool sim_strip_eligible(const GemmArgs& a, int mode, bool aligned) {
     // measured against the tiled kernel (fp16, count-only / with scores): 40 x 63 units 0.043 / 0.058 vs 0.036 / 0.050 ms, 20 x 157 equal /
     // 0.069 vs 0.063, 79 x 125 0.097 / 0.135 vs 0.107 / 0.140, 157 x 313 (C4) 0.359 / 0.496 vs 0.464 / 0.571, 391 x 313 0.858 / 1.176 vs 1.124 / 1.387
     // (round 4, with the staged strip load, `tools/debug/time_strip_small.py`: 40 x 94 units [14.7 per CU] 52 / 69 us vs 56 / 63 tiled;
-    // 79 x 125 [38.6] 92 / 122 vs 98 / 131; 234 x 94 [86] 167 / 223 vs 223 / 267: without the score stores the strip form wins from ~12
-    // units per CU on)
-    const long per_cu = g_strip_mode >= 2 ? 8L : (a.out ? 24L : 12L);
-    return units >= per_cu * g_num_cus;
+    // 79 x 125 [38.6] 92 / 122 vs 98 / 131; 234 x 94 [86] 167 / 223 vs 223 / 267.  Without the score stores the strip form would win
+    // from ~12 units per CU on, but its dump list takes 96 bytes per hit lane: at C3 -- chance-level scores, 1 % of the pairs inside
+    // the band -- the default list overflows where the tiled kernel's 8-byte pairs fit.  One threshold for both modes.)
+    return units >= (g_strip_mode >= 2 ? 8L : 24L) * g_num_cus;
 }
 
 hipError_t launch_sim_strip(const GemmArgs& a, int mode, hipStream_t st) {
