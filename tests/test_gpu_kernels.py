@@ -711,6 +711,10 @@ def test_frame_fuse_grouped_equals_per_feature_launches():
     a = ops.frame_fuse_grouped(fr2, dev(l2, torch.int32), pr2, flags)[0]
     m2 = (torch.arange(F2, device='cuda')[None, :] < dev(l2, torch.int32)[:, None]).to(torch.float32)
     assert torch.equal(a, ops.frame_fuse_grouped(fr2, None, pr2, flags, mask=m2)[0])
+    with pytest.raises(ValueError):
+        ops.frame_fuse_grouped(fr2, None, pr2, flags, mask=m2[:, :F2 - 1])                    # a mask narrower than the frames
+    with pytest.raises(ValueError):
+        ops.frame_fuse_grouped(fr2, None, pr2, flags, mask=m2.t().contiguous().t())          # no unit column stride
 
 
 @pytest.mark.parametrize('H,d,act', [(8, 512, 'tanh'), (1, 64, None), (2, 256, 'relu'), (4, 128, 'sigmoid')])
