@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 19
+#define LAFF_ABI_VERSION 20
 
 enum {
     LAFF_OK = 0,
@@ -72,6 +72,12 @@ int laff_ctx_set_stream(laff_ctx* ctx, void* hip_stream);
 int laff_ctx_destroy(laff_ctx* ctx);
 /* host out: [0]=CU count, [1]=clock MHz, [2]=LDS bytes per CU-workgroup limit, [3]=wavefront size */
 int laff_device_info(laff_ctx* ctx, int out[4]);
+/* Measurement aid (no counterpart in the reference): a one-thread launch, ordered on the ctx's stream like every other call and
+ * capturable in a HIP graph, that writes the device's constant-rate wall clock (s_memrealtime) to *slot (device memory).  bench.py puts
+ * one in front of and behind every launch of a captured step: the differences are the durations of the kernels as the graph runs
+ * them (this runtime refuses event-record nodes in a capture).  laff_wall_clock_khz: ticks per millisecond of that clock. */
+int laff_stamp(laff_ctx* ctx, unsigned long long* slot /*device*/);
+int laff_wall_clock_khz(laff_ctx* ctx, int* khz /*host*/);
 
 /* ---- a1: TransformNet.forward (model/model.py:257-276), eval mode ------------------------------------
  * Y[N,D] = (act(X[N,Dk] . W[D,Dk]^T + bias)) * bn_scale + bn_shift

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get('LAFF_HIP_LIB') or os.path.join(_HERE, 'lib', 'liblaff
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class Plane(C.Structure):
@@ -55,6 +55,8 @@ SIGNATURES = {
     'laff_ctx_set_stream': (C.c_int, [_P, _P]),
     'laff_ctx_destroy': (C.c_int, [_P]),
     'laff_device_info': (C.c_int, [_P, C.POINTER(_I)]),
+    'laff_stamp': (C.c_int, [_P, _P]),
+    'laff_wall_clock_khz': (C.c_int, [_P, C.POINTER(_I)]),
     'laff_fc_act_bn': (C.c_int, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I]),
     'laff_fc_act_bn_grouped': (C.c_int, [_P, C.POINTER(FcProblem), _I]),
     'laff_fc_gather_act_bn': (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I]),

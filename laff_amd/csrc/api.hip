@@ -134,6 +134,26 @@ int laff_ctx_destroy(laff_ctx* ctx) {
     return LAFF_OK;
 }
 
+namespace {
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+}  // namespace
+
+int laff_stamp(laff_ctx* ctx, unsigned long long* slot) {
+    CHECK_CTX(ctx);
+    if (!slot) return fail(LAFF_E_ARG, "laff_stamp: null slot");
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ctx->stream, slot);
+    HIP_TRY(hipGetLastError());
+    return LAFF_OK;
+}
+
+int laff_wall_clock_khz(laff_ctx* ctx, int* khz) {
+    CHECK_CTX(ctx);
+    if (!khz) return fail(LAFF_E_ARG, "laff_wall_clock_khz: null out");
+    HIP_TRY(hipDeviceGetAttribute(khz, hipDeviceAttributeWallClockRate, ctx->device));
+    return LAFF_OK;
+}
+
 int laff_device_info(laff_ctx* ctx, int out[4]) {
     CHECK_CTX(ctx);
     if (!out) return fail(LAFF_E_ARG, "laff_device_info: null out");
@@ -403,7 +423,11 @@ int laff_fc_act_bn_fused_grouped(laff_ctx* ctx, const laff_fc_fused_problem* pro
         a.out = q.Y; a.ldo = q.ldy; a.scale = 1.0f;
         a.row_scale = q.x_rscale; a.col_scale = q.w_rscale;
         a.bias = q.bias; a.bn_scale = q.bn_scale; a.bn_shift = q.bn_shift; a.act = q.act;
-        if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);   // debug builds only
+#ifdef LAFF_GEMM_TRACE
+    #ifdef LAFF_GEMM_TRACE
+    if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
+#endif
         ga.p[ga.count++] = a;
         if (ga.count == laff::MAX_GROUP) {
             HIP_TRY(laff::launch_gemm_nt_x3_fused_grouped(ga, ctx->stream));
@@ -741,7 +765,9 @@ static int sim_gemm_impl(laff_ctx* ctx, const char* who, const void* T, const vo
     a.out = S; a.ldo = lds; a.scale = scale;
     a.gt_col = gt_col; a.col0 = col0; a.s_gt = s_gt; a.count = gt_col ? count : nullptr;
     a.s_gt64 = s_gt64; a.band_r = band_t; a.band_c = band_v; a.pairs = pairs; a.pair_cap = pair_cap;
+#ifdef LAFF_GEMM_TRACE
     if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
     int mode = laff::GEMM_F32;
     if (precision == LAFF_PREC_FP16 || precision == LAFF_PREC_FP16X3) mode = laff::GEMM_F16;
     if (precision == LAFF_PREC_BF16 || precision == LAFF_PREC_BF16X3) mode = laff::GEMM_BF16;

@@ -759,7 +759,9 @@ hipError_t launch_fc_strip(FcStripArgs& a, int act, hipStream_t st) {
     if (U >= (1l << 31)) return hipErrorInvalidValue;
     a.total_units = (int)U;
     a.trace = nullptr;
-    if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);   // debug builds only
+#ifdef LAFF_FCS_TRACE
+    if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
     const int G = (int)std::min<long>(std::min(g_num_cus, STRIP_MAX_WG), U);
     a.nranges = G;
     // Workgroup b runs on XCD b % 8 (observed; only speed depends on it): XCD x takes the contiguous eighth x of the ranges, so its L2
@@ -767,12 +769,8 @@ hipError_t launch_fc_strip(FcStripArgs& a, int act, hipStream_t st) {
     for (int b = 0; b < G; ++b) a.range_of_wg[b] = (unsigned short)((G % 8 == 0) ? (b % 8) * (G / 8) + b / 8 : b);
 #define LAFF_FCS_LAUNCH(K)                                                                                                    \
     do {                                                                                                                      \
-        static bool attr = false;                                                                                             \
-        if (!attr) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute((const void*)fc_strip_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM); \
-            if (e != hipSuccess) return e;                                                                                    \
-            attr = true;                                                                                                      \
-        }                                                                                                                     \
+        static unsigned long long attr_done = 0;                                                                              \
+        if (hipError_t e = smem_attr_once(attr_done, fc_strip_kernel<K>, SMEM); e != hipSuccess) return e;                    \
         hipLaunchKernelGGL((fc_strip_kernel<K>), dim3((unsigned)G), dim3(256), SMEM, st, a);                                  \
     } while (0)
     if (act == LAFF_ACT_TANH || act == LAFF_ACT_SIGMOID) LAFF_FCS_LAUNCH(ACT_EXP);

@@ -1517,22 +1517,12 @@ __global__ __launch_bounds__(CF::THREADS, CF::WPS) void gemm_nt_grouped_kernel(G
     gemm_tile<MODE, STG, CF, EPI_FC>(g.p[p], r0, c0, smem);
 }
 
-template <typename K>
-static hipError_t set_smem(K kernel, int smem) {
-    if (smem > 64 * 1024) return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    return hipSuccess;
-}
-
 template <int MODE, int STG, typename CF>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t st) {
     const long nb = (long)((a.nR + CF::TR - 1) / CF::TR) * ((a.nC + CF::TC - 1) / CF::TC);
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
-    static bool attr_set = false;          // once per instantiation; also keeps the call out of HIP-graph captures
-    if (!attr_set) {
-        hipError_t e = set_smem(gemm_nt_kernel<MODE, STG, CF>, CF::SMEM + PAIR_LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;     // per device; also keeps the call out of HIP-graph captures
+    if (hipError_t e = smem_attr_once(attr_done, gemm_nt_kernel<MODE, STG, CF>, CF::SMEM + PAIR_LDS); e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_nt_kernel<MODE, STG, CF>), dim3((unsigned)nb), dim3(CF::THREADS), CF::SMEM + PAIR_LDS, st, a);
     return hipGetLastError();
 }
@@ -1599,12 +1589,8 @@ static hipError_t launch_grouped_f16_t(GroupedGemmArgs& g, hipStream_t st) {
     }
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
     g.tile_start[g.count] = (int)nb;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = set_smem(gemm_nt_grouped_kernel<GEMM_F16, 2, CF>, CF::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;     // per device; also keeps the call out of HIP-graph captures
+    if (hipError_t e = smem_attr_once(attr_done, gemm_nt_grouped_kernel<GEMM_F16, 2, CF>, CF::SMEM); e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_nt_grouped_kernel<GEMM_F16, 2, CF>), dim3((unsigned)nb), dim3(CF::THREADS), CF::SMEM, st, g);
     return hipGetLastError();
 }
@@ -1622,12 +1608,8 @@ static hipError_t launch_grouped_x3(GroupedGemmArgs& g, hipStream_t st) {
     g.nbig = (int)nb;
     if (g_gemm_variant != 4 && nb > g_num_cus && rem > 0 && rem * 4 <= 3L * g_num_cus) g.nbig = (int)(nb - rem);
     const long grid = g.nbig + 4L * (nb - g.nbig);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = set_smem(gemm_nt_x3_grouped_kernel<GEMM_F16>, CfgX3::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;     // per device; also keeps the call out of HIP-graph captures
+    if (hipError_t e = smem_attr_once(attr_done, gemm_nt_x3_grouped_kernel<GEMM_F16>, CfgX3::SMEM); e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_nt_x3_grouped_kernel<GEMM_F16>), dim3((unsigned)grid), dim3(CfgX3::THREADS), CfgX3::SMEM, st, g);
     return hipGetLastError();
 }
@@ -1641,12 +1623,8 @@ hipError_t launch_gemm_nt_x3_fused_grouped(GroupedGemmArgs& g, hipStream_t st) {
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
     g.tile_start[g.count] = (int)nb;
     g.nbig = (int)nb;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = set_smem(gemm_nt_x3_fused_grouped_kernel<GEMM_F16>, CfgX3::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;     // per device; also keeps the call out of HIP-graph captures
+    if (hipError_t e = smem_attr_once(attr_done, gemm_nt_x3_fused_grouped_kernel<GEMM_F16>, CfgX3::SMEM); e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_nt_x3_fused_grouped_kernel<GEMM_F16>), dim3((unsigned)nb), dim3(CfgX3::THREADS), CfgX3::SMEM, st, g);
     return hipGetLastError();
 }
@@ -1655,12 +1633,8 @@ template <int MODE>
 static hipError_t launch_x3(const GemmArgs& a, hipStream_t st) {
     const long nb = (long)((a.nR + CfgX3::TR - 1) / CfgX3::TR) * ((a.nC + CfgX3::TC - 1) / CfgX3::TC);
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = set_smem(gemm_nt_x3_kernel<MODE>, CfgX3::SMEM + PAIR_LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;     // per device; also keeps the call out of HIP-graph captures
+    if (hipError_t e = smem_attr_once(attr_done, gemm_nt_x3_kernel<MODE>, CfgX3::SMEM + PAIR_LDS); e != hipSuccess) return e;
     hipLaunchKernelGGL((gemm_nt_x3_kernel<MODE>), dim3((unsigned)nb), dim3(CfgX3::THREADS), CfgX3::SMEM + PAIR_LDS, st, a);
     return hipGetLastError();
 }

@@ -7,6 +7,24 @@
 
 namespace laff {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one flag word per kernel instantiation, one bit per device
+// ordinal (a second laff_ctx on another GPU of the same process sets it again).  The first launch of an instantiation on a device must
+// therefore happen outside a HIP-graph capture (every caller warms up eagerly before it captures).
+template <typename K>
+static inline hipError_t smem_attr_once(unsigned long long& done, K kernel, int smem) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return hipSuccess;
+    if (smem > 64 * 1024) {
+        e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+    }
+    done |= bit;
+    return hipSuccess;
+}
+
 enum { GEMM_F32 = 0, GEMM_F16 = 1, GEMM_BF16 = 2 };
 
 struct GemmArgs {

@@ -946,7 +946,9 @@ hipError_t launch_sim_strip(const GemmArgs& a, int mode, hipStream_t st) {
     s.gt_col = a.gt_col; s.col0 = a.col0; s.s_gt64 = a.s_gt64; s.band_r = a.band_r; s.band_c = a.band_c; s.count = a.count;
     s.pairs = a.pairs; s.pair_cap = a.pair_cap;
     s.debug = g_strip_mode;
+#ifdef LAFF_STRIP_TRACE
     if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) s.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
     const int NB = (a.nC + CB - 1) / CB, NS = (a.nR + SR - 1) / SR;
     const long U = (long)NS * NB;
     int G = (int)std::min<long>(std::min(g_num_cus, STRIP_MAX_WG), U);
@@ -968,13 +970,8 @@ hipError_t launch_sim_strip(const GemmArgs& a, int mode, hipStream_t st) {
     const bool hs = a.out != nullptr;
 #define LAFF_STRIP_LAUNCH(M, BD, HS, S1)                                                                                      \
     do {                                                                                                                      \
-        static bool attr = false;                                                                                             \
-        if (!attr) {                                                                                                          \
-            hipError_t e = hipFuncSetAttribute((const void*)sim_strip_kernel<M, BD, HS, S1>,                                  \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);                             \
-            if (e != hipSuccess) return e;                                                                                    \
-            attr = true;                                                                                                      \
-        }                                                                                                                     \
+        static unsigned long long attr_done = 0;                                                                              \
+        if (hipError_t e = smem_attr_once(attr_done, sim_strip_kernel<M, BD, HS, S1>, SMEM); e != hipSuccess) return e;       \
         hipLaunchKernelGGL((sim_strip_kernel<M, BD, HS, S1>), dim3((unsigned)G), dim3(256), SMEM, st, s);                     \
     } while (0)
 #define LAFF_STRIP_MODE(M)                                                                                                    \

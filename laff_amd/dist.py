@@ -41,6 +41,58 @@ def shard_bounds(n, world, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
+class TorchComm:
+    """The collectives of a pass on a torch.distributed group (backend 'nccl' = RCCL; 'gloo' in the CPU tests)."""
+
+    def __init__(self, group=None, force=False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.active = self.world > 1 or (force and dist.is_initialized())
+
+    def all_gather(self, out, send, async_op=False):
+        return dist.all_gather_into_tensor(out, send, group=self.group, async_op=async_op)
+
+    def all_reduce(self, t, op):
+        dist.all_reduce(t, op={'max': dist.ReduceOp.MAX, 'sum': dist.ReduceOp.SUM}[op], group=self.group)
+
+    def all_to_all(self, out, send):
+        dist.all_to_all_single(out, send, group=self.group)
+
+
+class EmulatedComm:
+    """ONE rank's share of a `world`-rank pass on one device, without a process group (bench.py --emulate-shard): every collective is
+    replaced by what it would leave on this rank -- an all-gather copies this rank's block into its slot of the output, whose other
+    slots the caller has pre-filled with the peers' rows (the outputs live in the pass's `state` dict under fixed keys); an
+    all-reduce combines with `peers[op]`, the peers' combined contribution (a tensor, or absent = nothing to add).  The kernels, their
+    shapes and the bytes they move are exactly one rank's; what is missing is the wire time.  Everything here is capturable in a HIP
+    graph."""
+
+    def __init__(self, world, rank=0, peers=None):
+        self.world, self.rank, self.active, self.group = int(world), int(rank), True, None
+        self.peers = peers if peers is not None else {}
+
+    def all_gather(self, out, send, async_op=False):
+        n = send.shape[0]
+        out[self.rank * n:(self.rank + 1) * n].copy_(send)
+        return None
+
+    def all_reduce(self, t, op):
+        other = self.peers.get(op)
+        if other is not None:
+            if op == 'max':
+                torch.maximum(t, other, out=t)
+            else:
+                t.add_(other)
+
+    def all_to_all(self, out, send):
+        raise NotImplementedError("EmulatedComm covers the 'video' and 'text' schemes")
+
+
+def _comm_of(group, comm, force_collectives):
+    return comm if comm is not None else TorchComm(group, force_collectives)
+
+
 class HipBackend:
     """Per-rank compute on liblaff_hip.so."""
 
@@ -152,6 +204,8 @@ class HipBackend:
 
     def v16_rows(self, T):
         """the operand as (N, K * 2) bytes: what is all-gathered"""
+        if T.precision not in ('fp16', 'bf16'):
+            raise ValueError("'video16' needs a one-plane 16-bit operand, got %r" % T.precision)
         return T.buf[:T.N * T.K * 2].view(T.N, T.K * 2)
 
     def v16_operand(self, rows2d, N, like):
@@ -253,6 +307,12 @@ def choose_sharding(Nt, Nv):
     return 'text' if Nv <= Nt else 'video'
 
 
+def default_pair_bucket_cap(Nt, world):
+    """Slots of one (sender, owner) bucket of 'video16''s pair all-to-all: the even share of 128 pairs per text (the headroom of
+    ops.default_pair_cap: C4 lists 2.4 pairs per text, chance-level scores as in C3 ~30), at least 4096, a multiple of 4."""
+    return max(4096, (128 * int(Nt) // max(world * world, 1) + 3) & ~3)
+
+
 def _flat_rows(E):
     return E.reshape(E.shape[0], -1)
 
@@ -278,7 +338,7 @@ def _compact(gathered, sizes, nmax, heads):
 
 def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
                      timer=None, want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False,
-                     finish_tag=''):
+                     finish_tag='', comm_impl=None):
     """One pass of the hot path on this rank's shards, videos sharded ('video' scheme of the module docstring).
     gt: (Nt,) int32 GLOBAL video column of every text (replicated).
 
@@ -286,10 +346,10 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
     with a GraphRunner.  force_collectives runs the collectives even on a 1-rank group (used to exercise the N > 1 code
     path on a single GPU).  finish_tag names the captured 'finish' phase: callers that alternate between several metrics_out
     buffers (to keep a step in flight while the host reads the previous one) pass a different tag per buffer.
+    comm_impl: None (torch.distributed on `group`) or an EmulatedComm (one rank's share of a larger pass on one device).
     Returns dict(S_local (Nt, v1-v0), col0, ranks (Nt,), metrics)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    comm = world > 1 or (force_collectives and dist.is_initialized())
+    cx = _comm_of(group, comm_impl, force_collectives)
+    world, rank, comm = cx.world, cx.rank, cx.active
     v0, v1 = shard_bounds(Nv, world, rank)
     mark = timer.mark if timer is not None else (lambda name: None)
     run = runner if runner is not None else _eager
@@ -329,7 +389,7 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
                 if 'gathered' not in state or tuple(state['gathered'].shape) != shape:
                     state['gathered'] = torch.empty(shape, dtype=send.dtype, device=send.device)
                 gathered = state['gathered']
-                work = dist.all_gather_into_tensor(gathered, send, group=group, async_op=True)     # overlaps the video tower
+                work = cx.all_gather(gathered, send, async_op=True)     # overlaps the video tower
 
             def video_phase():
                 vis_emb = compute.embed_video(vis_feats_local)
@@ -357,14 +417,14 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
         st = run('prep', prep_phase)
         mark('prep')
         if comm:
-            dist.all_reduce(compute.s_gt_of(st), op=dist.ReduceOp.MAX, group=group)
+            cx.all_reduce(compute.s_gt_of(st), 'max')
             mark('allreduce_s_gt')
         S_local, count = run('sim', lambda: compute.sim_ranked(st, want_scores))
         mark('sim_gemm')
         if comm:
             # an overflowing pair list poisons count[0] with -(2^26) on every rank it happens on (rank.hip: rank_resolve_kernel); the
             # SUM of up to 16 such poisons stays negative, so the rank < 1 flag of the metrics kernel still trips after the reduction
-            dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)
+            cx.all_reduce(count, 'sum')
             mark('allreduce_count')
 
         metrics = None
@@ -392,15 +452,14 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
 
 def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True,
                              want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False,
-                             finish_tag='', timer=None):
+                             finish_tag='', timer=None, comm_impl=None):
     """The 'text' scheme of the module docstring: rank g owns texts [t0, t1) end to end and the ROW block S[t0:t1, :]; videos are
     split for the embedding stage only and ONE all-gather of the fp32 VIDEO embeddings (Nv x K: a quarter of the text side at C4)
     gives every rank all videos.  Every text then meets its ground-truth video locally, so neither the MAX all-reduce of s_gt
     nor the SUM all-reduce of the counts is needed; the ranks (Nt int32) are all-gathered for the replicated metrics.
     Returns dict(S_local (t1-t0, Nv), row0, ranks (Nt,), metrics)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    comm = world > 1 or (force_collectives and dist.is_initialized())
+    cx = _comm_of(group, comm_impl, force_collectives)
+    world, rank, comm = cx.world, cx.rank, cx.active
     t0, t1 = shard_bounds(Nt, world, rank)
     mark = timer.mark if timer is not None else (lambda name: None)
     run = runner if runner is not None else _eager
@@ -431,7 +490,7 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
             if 'gathered_v' not in state or tuple(state['gathered_v'].shape) != shape:
                 state['gathered_v'] = torch.empty(shape, dtype=send.dtype, device=send.device)
             gathered = state['gathered_v']
-            dist.all_gather_into_tensor(gathered, send, group=group)
+            cx.all_gather(gathered, send)
         mark('all_gather_wait')
         # this rank's slice of the ground-truth columns lives in `state`: a captured phase reads it at a fixed address on every
         # replay, and it is refreshed from `gt` on every step (outside the captured phase) like the 'video' scheme reads gt live
@@ -460,7 +519,7 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
             if 'gathered_r' not in state or state['gathered_r'].numel() != world * tmax:
                 state['gathered_r'] = torch.empty(world * tmax, dtype=torch.int32, device=mine.device)
             all_ranks = state['gathered_r']
-            dist.all_gather_into_tensor(all_ranks, mine, group=group)
+            cx.all_gather(all_ranks, mine)
             mark('allgather_ranks')
         else:
             all_ranks = mine
@@ -483,7 +542,7 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
             'rank_state': st}
 
 
-def _all_gather_rows(x2d, nmax, world, comm, group, state, key, async_op=False):
+def _all_gather_rows(x2d, nmax, world, comm, cx, state, key, async_op=False):
     """all-gather of equally padded row blocks; returns (gathered (world * nmax, cols) or x2d itself, work or None)"""
     if not comm:
         return x2d, None
@@ -491,7 +550,7 @@ def _all_gather_rows(x2d, nmax, world, comm, group, state, key, async_op=False):
     shape = (world * nmax, send.shape[1])
     if key not in state or tuple(state[key].shape) != shape or state[key].dtype != send.dtype:
         state[key] = torch.empty(shape, dtype=send.dtype, device=send.device)
-    work = dist.all_gather_into_tensor(state[key], send, group=group, async_op=async_op)
+    work = cx.all_gather(state[key], send, async_op=async_op)
     return state[key], (work if async_op else None)
 
 
@@ -503,15 +562,23 @@ def _compact2d(gathered, sizes, nmax):
 
 def evaluate_sharded_v16(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, heads, group=None, want_metrics=True, timer=None,
                          want_scores=True, metrics_out=None, runner=None, state=None, force_collectives=False, finish_tag='',
-                         pair_bucket_cap=None):
+                         pair_bucket_cap=None, comm_impl=None):
     """The 'video16' scheme of the module docstring: rank g owns videos [v0, v1) and the column block S[:, v0:v1] as in
     evaluate_sharded, but the text side crosses the links as the 16-bit operand; exact re-scores happen at the text owners.
-    pair_bucket_cap: slots of one (sender, owner) bucket of the pair all-to-all (default: the even share of 32 pairs per text -- C4 lists
-    2.4 per text --, at least 4096).
+    pair_bucket_cap: slots of one (sender, owner) bucket of the pair all-to-all (default_pair_bucket_cap: the even share of 128 pairs
+    per text, at least 4096).  A bucket that fills up poisons count[0]: the pass ends in check_metrics_flag's RuntimeError (or, with
+    want_metrics=False, in a rank < 1) -- call again with a larger pair_bucket_cap; `pair_fill` in the result tells how full they were.
+    Needs a one-plane 16-bit operand (fp16 / bf16): ValueError otherwise.
+    S_local: the in-band pairs are re-scored at the owner of their TEXT row, which holds no part of S, so S_local keeps the 16-bit
+    GEMM's value for them (inside the band of the exact score) -- only the ground-truth entries carry the exact score.  Ranks
+    recounted from S_local can therefore differ from the exact `ranks` returned here by the pairs inside the band; the 'video' and
+    'text' schemes patch S and do agree.
     Returns dict(S_local (Nt, v1 - v0), col0, ranks (Nt,), metrics, gathered_bytes)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    comm = world > 1 or (force_collectives and dist.is_initialized())
+    if hasattr(compute, 'v16_ok') and not compute.v16_ok():
+        raise ValueError("evaluate_sharded_v16 gathers a one-plane 16-bit operand: precision must be 'fp16' or 'bf16', not %r"
+                         % getattr(compute, 'precision', None))
+    cx = _comm_of(group, comm_impl, force_collectives)
+    world, rank, comm = cx.world, cx.rank, cx.active
     mark = timer.mark if timer is not None else (lambda name: None)
     run = runner if runner is not None else _eager
     state = state if state is not None else {}
@@ -524,7 +591,7 @@ def evaluate_sharded_v16(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, 
     tmax = max(hi - lo for lo, hi in tsizes)
     vmax = max(hi - lo for lo, hi in vsizes)
     if pair_bucket_cap is None:
-        pair_bucket_cap = max(4096, (32 * Nt // max(world * world, 1) + 3) & ~3)
+        pair_bucket_cap = default_pair_bucket_cap(Nt, world)
     cap = (int(pair_bucket_cap) + 3) & ~3
     if hasattr(compute, 'set_unpacked'):
         compute.set_unpacked(None)
@@ -544,7 +611,7 @@ def evaluate_sharded_v16(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, 
             return txt_emb, T, compute.v16_rows(T)
         txt_emb, T_local, t_rows = run('text16', text_phase)
         mark('txt_tower')
-        t_all, w1 = _all_gather_rows(t_rows, tmax, world, comm, group, state, 'g_t16', async_op=True)
+        t_all, w1 = _all_gather_rows(t_rows, tmax, world, comm, cx, state, 'g_t16', async_op=True)
 
         def video_phase():
             vis_emb = compute.embed_video(vis_feats_local)
@@ -552,7 +619,7 @@ def evaluate_sharded_v16(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, 
             return vis_emb, V, compute.v16_band_video(vis_emb, V), _flat_rows(vis_emb)
         vis_emb, V_local, band_v, v_rows = run('video16', video_phase)
         mark('vis_tower')
-        v_all, w2 = _all_gather_rows(v_rows, vmax, world, comm, group, state, 'g_v32', async_op=True)
+        v_all, w2 = _all_gather_rows(v_rows, vmax, world, comm, cx, state, 'g_v32', async_op=True)
         for w in (w1, w2):
             if w is not None:
                 w.wait()
@@ -568,7 +635,7 @@ def evaluate_sharded_v16(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, 
             return Ev_all, s_gt64, band_t, pay
         Ev_all, s_gt64_l, band_t_l, pay = run('owner16', owner_phase)
         mark('prep')
-        pay_all, _ = _all_gather_rows(pay, tmax, world, comm, group, state, 'g_pay')
+        pay_all, _ = _all_gather_rows(pay, tmax, world, comm, cx, state, 'g_pay')
         mark('allgather_sgt_band')
 
         # ---- the video owner: banded GEMM of ALL texts x its videos; pairs inside the band -> buckets per text owner ----
@@ -593,16 +660,21 @@ def evaluate_sharded_v16(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, 
                 state['recv'] = torch.empty(4 + 2 * world * cap, dtype=torch.int32, device=send.device)
                 state['recv'][:4] = torch.tensor([0, 0, world * cap, 4], dtype=torch.int32, device=send.device)
             lst = state['recv']
-            dist.all_to_all_single(lst[4:].view(world, cap, 2), send, group=group)
-            dist.all_reduce(count, op=dist.ReduceOp.SUM, group=group)          # (a full bucket poisons count[0]: stays negative)
+            cx.all_to_all(lst[4:].view(world, cap, 2), send)
+            cx.all_reduce(count, 'sum')          # (a full bucket poisons count[0]: stays negative)
             mark('alltoall_pairs')
         else:
-            lst = torch.empty(4 + 2 * cap, dtype=torch.int32, device=send.device)
-            lst[:4] = torch.tensor([0, 0, cap, 4], dtype=torch.int32, device=send.device)
-            lst[4:] = send.reshape(-1)
+            # one rank, no collectives: the list lives in `state` (a captured resolve phase reads it at a fixed address on every replay)
+            # and is refilled from this step's buckets INSIDE that phase
+            if 'lst_local' not in state or state['lst_local'].numel() != 4 + 2 * world * cap or state['lst_local'].device != send.device:
+                state['lst_local'] = torch.empty(4 + 2 * world * cap, dtype=torch.int32, device=send.device)
+                state['lst_local'][:4] = torch.tensor([0, 0, world * cap, 4], dtype=torch.int32, device=send.device)
+            lst = state['lst_local']
 
         # ---- the text owner: exact re-score of the pairs of its rows; ranks -> everybody ----
         def resolve_phase():
+            if not comm:
+                lst[4:].copy_(send.reshape(-1))
             mine = count[t0:t1].clone()
             compute.v16_resolve(txt_emb, Ev_all, s_gt64_l, mine, lst)
             r = (mine + 1).to(torch.int32)
@@ -616,7 +688,7 @@ def evaluate_sharded_v16(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, 
             if 'g_ranks' not in state or state['g_ranks'].numel() != world * tmax:
                 state['g_ranks'] = torch.empty(world * tmax, dtype=torch.int32, device=mine.device)
             all_ranks = state['g_ranks']
-            dist.all_gather_into_tensor(all_ranks, mine, group=group)
+            cx.all_gather(all_ranks, mine)
             mark('allgather_ranks')
         else:
             all_ranks = mine

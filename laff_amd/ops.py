@@ -43,6 +43,19 @@ def _context(device):
     return lib, h
 
 
+def stamp(slots, i):
+    """laff_stamp: the device wall clock into slots[i] (int64 device tensor), ordered on the current stream, capturable."""
+    lib, h = _context(slots.device)
+    check(lib.laff_stamp(h, C.c_void_p(slots.data_ptr() + 8 * int(i))))
+
+
+def wall_clock_khz(device):
+    lib, h = _context(device)
+    khz = C.c_int()
+    check(lib.laff_wall_clock_khz(h, C.byref(khz)))
+    return int(khz.value)
+
+
 def reset_contexts():
     """Destroys the cached laff_ctx handles; the next call creates fresh ones (the LAFF_* environment knobs are read then)."""
     lib = _lib.load()
@@ -1047,7 +1060,7 @@ def rank_metrics(rank1, base=0, ranks_out=None):
     _dev(rank1, 'rank1', torch.int32)
     out = (C.c_double * 7)()
     lib, h = _context(rank1.device)
-    check(lib.laff_rank_metrics(h, _ptr(rank1.contiguous()), rank1.numel(), int(base), _ptr(_ranks_out(rank1, ranks_out)), out))
+    _call('rank_metrics', lib.laff_rank_metrics, h, _ptr(rank1.contiguous()), rank1.numel(), int(base), _ptr(_ranks_out(rank1, ranks_out)), out)
     return tuple(out)
 
 
@@ -1062,8 +1075,8 @@ def rank_metrics_async(rank1, out_pinned, base=0, ranks_out=None):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError('call ops.ctx_prepare_metrics(device) before capturing a graph (it allocates scratch)')
         ctx_prepare_metrics(rank1.device)
-    check(lib.laff_rank_metrics_async(h, _ptr(rank1.contiguous()), rank1.numel(), int(base), _ptr(_ranks_out(rank1, ranks_out)),
-                                      C.c_void_p(out_pinned.data_ptr())))
+    _call('rank_metrics', lib.laff_rank_metrics_async, h, _ptr(rank1.contiguous()), rank1.numel(), int(base), _ptr(_ranks_out(rank1, ranks_out)),
+          C.c_void_p(out_pinned.data_ptr()))
 
 
 def ctx_prepare_metrics(device):

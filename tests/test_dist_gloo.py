@@ -153,3 +153,50 @@ def test_video16_full_bucket_poisons_the_ranks():
     res = evaluate_sharded_v16(OracleBackend(Wt, Wv), {'x': torch.from_numpy(xv)}, {'x': torch.from_numpy(xt)},
                                torch.from_numpy(gt), len(xt), len(xv), 1, pair_bucket_cap=4, want_metrics=False)
     assert int(res['pair_fill'][1]) == 1 and int(res['ranks'][0]) < 1
+
+
+@pytest.mark.parametrize('world,rank', [(3, 0), (3, 2), (8, 5)])
+def test_emulated_rank_of_a_sharded_pass(world, rank):
+    """EmulatedComm (bench.py --emulate-shard): one rank's share of a `world`-rank pass in a single process, the collectives replaced by
+    what they would leave on this rank.  With the peers' contributions pre-filled the emulated rank reproduces the single-process
+    ranks in both decompositions (uneven shards: 61 texts / 23 videos)."""
+    from laff_amd.dist import EmulatedComm
+    xt, xv, gt, Wt, Wv = _problem()
+    Nt, Nv = len(xt), len(xv)
+    be = OracleBackend(Wt, Wv)
+    gt_t = torch.from_numpy(gt)
+    single = evaluate_sharded(be, {'x': torch.from_numpy(xv)}, {'x': torch.from_numpy(xt)}, gt_t, Nt, Nv, 1)
+    t0, t1 = shard_bounds(Nt, world, rank)
+    v0, v1 = shard_bounds(Nv, world, rank)
+    vis_l, txt_l = {'x': torch.from_numpy(xv[v0:v1])}, {'x': torch.from_numpy(xt[t0:t1])}
+    tmax = max(b - a for a, b in (shard_bounds(Nt, world, r) for r in range(world)))
+    vmax = max(b - a for a, b in (shard_bounds(Nv, world, r) for r in range(world)))
+
+    def padded(E, n, nmax):
+        out = torch.zeros((world * nmax, E.shape[1]), dtype=E.dtype)
+        for r in range(world):
+            a, b = shard_bounds(n, world, r)
+            out[r * nmax:r * nmax + (b - a)] = E[a:b]
+        return out
+
+    # 'video': the text rows of the peers are in the gather buffer, the peers' exact ground-truth scores and counts in `peers`
+    full_prep = be.prepare(single['txt_emb'], single['vis_emb'], None, None, gt_t, 0)
+    state = {'gathered': padded(single['txt_emb'].reshape(Nt, -1), Nt, tmax)}
+    state['gathered'][rank * tmax:(rank + 1) * tmax] = -7.0                      # this rank's slot is filled by the pass itself
+    comm = EmulatedComm(world, rank, {'max': full_prep.s_gt64.clone()})
+    first = evaluate_sharded(be, vis_l, txt_l, gt_t, Nt, Nv, 1, state=state, comm_impl=comm, want_metrics=False)
+    comm.peers['sum'] = (single['ranks'] - first['ranks']).to(torch.int32)      # what the other ranks' blocks add
+    res = evaluate_sharded(be, vis_l, txt_l, gt_t, Nt, Nv, 1, state=state, comm_impl=comm)
+    assert np.array_equal(res['ranks'].numpy(), single['ranks'].numpy())
+    np.testing.assert_allclose(res['metrics'], np.array(single['metrics']), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res['S_local'].numpy(), single['S_local'].numpy()[:, v0:v1], rtol=0, atol=1e-6)
+    assert int((first['ranks'] <= single['ranks']).all())
+
+    # 'text': the video rows of the peers are in the gather buffer, the peers' ranks in the rank buffer
+    state = {'gathered_v': padded(single['vis_emb'].reshape(Nv, -1), Nv, vmax),
+             'gathered_r': padded(single['ranks'].to(torch.int32)[:, None], Nt, tmax).reshape(-1)}
+    state['gathered_v'][rank * vmax:(rank + 1) * vmax] = -7.0
+    state['gathered_r'][rank * tmax:(rank + 1) * tmax] = 0
+    res = evaluate_sharded_by_text(be, vis_l, txt_l, gt_t, Nt, Nv, 1, state=state, comm_impl=EmulatedComm(world, rank))
+    assert np.array_equal(res['ranks'].numpy(), single['ranks'].numpy())
+    np.testing.assert_allclose(res['S_local'].numpy(), single['S_local'].numpy()[t0:t1], rtol=0, atol=1e-6)

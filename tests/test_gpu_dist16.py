@@ -85,6 +85,34 @@ def test_video16_every_rank_of_a_sharded_pass_emulated_on_one_device(Nt, Nv, pre
     assert torch.equal(got, ref_count)
 
 
+def test_video16_under_a_graph_runner_without_collectives():
+    """world == 1, no process group, per-phase HIP graphs: the resolve phase is captured once and must find this step's pair list at
+    the address it captured (the list lives in `state` and is refilled inside the phase).  Allocations between the replays move the
+    caching allocator's blocks around: a list allocated per call would be read after free."""
+    from laff_amd.dist import GraphRunner, HipBackend, evaluate_sharded, evaluate_sharded_v16
+    model, vis, txt, gt, Nt, Nv, H = _problem('c2_10kx3k')
+    backend = HipBackend(model, 'fp16')
+    ref = evaluate_sharded(backend, vis, txt, gt, Nt, Nv, H)
+    pinned = torch.zeros(8, dtype=torch.float64).pin_memory()
+    runner, state = GraphRunner(), {}
+    junk = []
+    for k in range(4):                           # capture, then three replays
+        out = evaluate_sharded_v16(backend, vis, txt, gt, Nt, Nv, H, runner=runner, state=state, metrics_out=pinned)
+        torch.cuda.synchronize()
+        assert torch.equal(out['ranks'], ref['ranks'])
+        np.testing.assert_allclose(pinned[:7].numpy(), ref['metrics'], rtol=1e-13)
+        assert pinned[7].item() == 0
+        junk.append(torch.full((1 << 18,), -1, dtype=torch.int32, device=DEV))      # lands where a freed per-call list would have been
+        junk.append(torch.full((4 + 2 * 4096 * (k + 1),), -1, dtype=torch.int32, device=DEV))
+
+
+def test_video16_refuses_split_operands():
+    from laff_amd.dist import HipBackend, evaluate_sharded_v16
+    model, vis, txt, gt, Nt, Nv, H = _problem('tiny')
+    with pytest.raises(ValueError, match='16-bit'):
+        evaluate_sharded_v16(HipBackend(model, 'fp16x3'), vis, txt, gt, Nt, Nv, H)
+
+
 def test_video16_on_one_rank_rccl_group():
     """The N > 1 code path of 'video16' (three all-gathers, the pair all-to-all, the count all-reduce, per-phase HIP graphs) on a 1-rank
     RCCL group: same ranks and metrics as the plain single-GPU pass."""
