@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 20
+#define LAFF_ABI_VERSION 21
 
 enum {
     LAFF_OK = 0,
@@ -350,6 +350,18 @@ int laff_sim_gemm_banded(laff_ctx* ctx, const void* T, const void* V, int Nt, in
                          int* count, unsigned* pairs, unsigned pair_cap);
 int laff_rank_resolve(laff_ctx* ctx, const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64,
                       int* count, float* S, int lds, unsigned* pairs, unsigned pair_cap);
+/* laff_rank_resolve and laff_rank_metrics[_async](count, base) in ONE launch, for passes in which nothing (no all-reduce of the counts)
+ * comes between them: the workgroup of the resolve launch that finishes last turns the final counts into ranks (ranks_out, nullable:
+ * count + base) and the seven metrics of evaluation.eval (/root/reference/evaluation.py:92-109) -- the label loop + eval of
+ * predictor.py:232-246 end in the same kernel that settles the last rank.  out8 (host): 7 metrics + flag as laff_rank_metrics_async.
+ *   synchronous == 0: returns at once; when out8 is pinned host memory (hipHostMalloc / hipHostRegister) the device writes it
+ *                     directly -- valid after the stream (or the graph the call was captured in) has completed --, otherwise a 64-byte
+ *                     copy is queued behind the launch.  Capturable (call it once eagerly first: the ctx allocates its result slots then).
+ *   synchronous != 0: waits for the stream; LAFF_E_ARG when the flag is set (a rank < 1: overflowed pair list).
+ * The fp64 mean of reciprocals is summed in this one workgroup's fixed order: equal to laff_rank_metrics to rounding (1e-16). */
+int laff_rank_resolve_metrics(laff_ctx* ctx, const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64,
+                              int* count, float* S, int lds, unsigned* pairs, unsigned pair_cap, int base, int* ranks_out,
+                              double* out8 /*host*/, int synchronous);
 
 /* s_gt[t] = S[t, gt_col[t]-col0] if that column is in [0,Nv) else -inf  (shard-local ground-truth score) */
 int laff_gather_gt(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0,

@@ -857,6 +857,46 @@ int laff_rank_resolve(laff_ctx* ctx, const float* Et, const float* Ev, int Nt, i
     return LAFF_OK;
 }
 
+int laff_rank_resolve_metrics(laff_ctx* ctx, const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64,
+                              int* count, float* S, int lds, unsigned* pairs, unsigned pair_cap, int base, int* ranks_out, double* out8,
+                              int synchronous) {
+    CHECK_CTX(ctx);
+    if (!out8) return fail(LAFF_E_ARG, "laff_rank_resolve_metrics: null out8");
+    if (Nt < 1 || Nv < 1) return fail(LAFF_E_SHAPE, "laff_rank_resolve_metrics: Nt=%d Nv=%d (the metrics of an empty query set are undefined)", Nt, Nv);
+    if (!Et || !Ev || !s_gt64 || !count || !pairs) return fail(LAFF_E_ARG, "laff_rank_resolve_metrics: null argument");
+    pair_cap &= ~3u;
+    if (H < 1 || d < 4 || (d & 3) || pair_cap < 4) return fail(LAFF_E_SHAPE, "laff_rank_resolve_metrics: bad shape");
+    if (S && lds < Nv) return fail(LAFF_E_SHAPE, "laff_rank_resolve_metrics: lds=%d < Nv=%d", lds, Nv);
+    if (!aligned16(Et) || !aligned16(Ev)) return fail(LAFF_E_ALIGN, "laff_rank_resolve_metrics: embeddings must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    if (int rc = metrics_buffers(ctx)) return rc;
+    const size_t si = synchronous ? 0 : 1 + ctx->metrics_slot++ % (METRIC_SLOTS - 1);
+    double* slot = ctx->d_metrics + 8 * si;
+    unsigned* ticket = (unsigned*)(ctx->d_mscratch + si * laff::rank_metrics_scratch_bytes() + laff::rank_resolve_ticket_offset());
+    // Pinned (hipHostMalloc'ed / registered) result buffers are addressable from the device: the finishing workgroup stores the 64 bytes
+    // there itself and no copy node follows the launch.  Anything else gets the copy.
+    double* host8 = nullptr;
+    if (!synchronous) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, out8, 0) == hipSuccess && dp) host8 = (double*)dp;
+        else (void)hipGetLastError();
+    }
+    HIP_TRY(laff::launch_rank_resolve(Et, Ev, Nt, Nv, H, d, s_gt64, count, S, lds, pairs, pair_cap, ctx->stream, Nt, base, ranks_out, slot,
+                                      host8, ticket));
+    if (synchronous) {
+        HIP_TRY(hipMemcpyAsync(ctx->h_metrics, slot, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_metrics[7] != 0.0)
+            return fail(LAFF_E_ARG, "laff_rank_resolve_metrics: a rank < 1 was found (the pair list of laff_sim_gemm_banded overflowed, or the "
+                                    "counts are corrupt)");
+        for (int i = 0; i < 7; ++i) out8[i] = ctx->h_metrics[i];
+        out8[7] = 0.0;
+    } else if (!host8) {
+        HIP_TRY(hipMemcpyAsync(out8, slot, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return LAFF_OK;
+}
+
 int laff_gather_gt(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt) {
     CHECK_CTX(ctx);
     if (Nt == 0) return LAFF_OK;                 /* empty problem: nothing to launch, pointers may be null */

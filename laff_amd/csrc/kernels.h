@@ -222,10 +222,14 @@ hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, 
                                float* band_v, int* zero_count, unsigned* pairs, int sides, hipStream_t st);
 hipError_t launch_rank_export(const double* s_gt64, int* count, float* S, int lds, unsigned* pairs, unsigned pair_cap, const int* bounds,
                               int world, int col0, unsigned* out, unsigned cap, unsigned* fill, hipStream_t st);
+// metrics_n > 0: the block that finishes last also turns the counts into ranks (count + base -> ranks_out) and the seven metrics
+// (out8 on the device, host8 = the same in device-addressable host memory or null); ticket: one zero word, left zero
 hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64, int* count,
-                               float* S, int lds, unsigned* pairs, unsigned pair_cap, hipStream_t st);
+                               float* S, int lds, unsigned* pairs, unsigned pair_cap, hipStream_t st, int metrics_n = 0, int base = 0,
+                               int* ranks_out = nullptr, double* out8 = nullptr, double* host8 = nullptr, unsigned* ticket = nullptr);
 // scratch: rank_metrics_scratch_bytes() bytes, zero before the first launch (every launch leaves it zero); not shared by launches in flight
 size_t rank_metrics_scratch_bytes();
+size_t rank_resolve_ticket_offset();      // where, inside that scratch, the ticket lines of the fused resolve + metrics launch start
 hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, unsigned* scratch, hipStream_t st);
 hipError_t launch_gather_gt(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt,
                             hipStream_t st);

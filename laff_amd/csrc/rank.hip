@@ -329,6 +329,260 @@ hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, 
 
 constexpr unsigned RESOLVE_QCAP = 512;           // queued pairs per wavefront (LDS)
 
+// ---- evaluation.eval (/root/reference/evaluation.py:92-109) by ONE workgroup, as the tail of the resolve launch -------------------
+// The block that draws the last ticket of laff_rank_resolve_metrics sees every count final (the other blocks released theirs before
+// taking a ticket) and turns them into ranks and the seven metrics itself: one launch and one ~6 us launch gap less than
+// laff_rank_resolve + laff_rank_metrics, no scratch round trips between blocks, and the 64 result bytes go straight into the caller's
+// pinned buffer when the device can address it (no copy node).  Same definitions as rank_metrics_kernel below; the fp64 sum of
+// reciprocals is taken in this block's own fixed order (thread-strided partials, xor-shuffle tree, waves in order), so it agrees with
+// the multi-block kernel to rounding (1e-16 relative), not bit for bit.
+struct MetricsTail {
+    int n;                 // 0: no tail (plain laff_rank_resolve)
+    int base;
+    int* ranks_out;        // [n] or null
+    double* out8;          // device: 7 metrics + flag
+    double* host8;         // the same 8 doubles in device-addressable host memory, or null
+    unsigned* ticket;      // RESOLVE_TICKET_BYTES, zero before the launch; left zero
+};
+constexpr unsigned RESOLVE_TICKET_GROUPS = 32;
+constexpr size_t RESOLVE_TICKET_BYTES = 256 * (1 + RESOLVE_TICKET_GROUPS);
+struct MetricsLds {
+    double shd[16];
+    unsigned long long shl[16][4];
+    int shm[16][2];
+    int wsum[4];
+    int sel[2];
+    unsigned hist[512 * 9];
+};
+constexpr size_t RESOLVE_POOL_BYTES = sizeof(MetricsLds) > 4 * RESOLVE_QCAP * 8 ? sizeof(MetricsLds) : 4 * RESOLVE_QCAP * 8;
+
+template <int NT>
+__device__ void metrics_single_block(const int* r, int n, int base, int* ranks_out, double* out8, double* host8, MetricsLds& L) {
+    static_assert(NT == 256, "select_bin below wants exactly four wavefronts");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // One CU does all of this with one wavefront per SIMD, so the per-rank work is kept to a handful of integer instructions (the
+    // first version -- reciprocal, sums and two histogram updates per rank -- took 19 us for 40,000 ranks).  L.hist is cut in three:
+    //   lo  [256 x 9]  ranks 1..255, eight replicas per bin (pitch 9): nearly all ranks of a retrieval that works; v == 1 (41 % at C4;
+    //                  64 lanes adding to one LDS word serialise) is counted in a register instead;
+    //   mid [2048]     ranks 256..2303, one word per rank;
+    //   hi  [256]      ranks from 2304 up by their top byte (bin min(v >> 8, 255)), and invalid ranks (< 1): the long path -- fp64
+    //                  reciprocal, sum, min / max per rank.
+    // R@1/5/10, the mean rank and the mean reciprocal rank of the ranks below 2304 are read off the 2,303 bins afterwards.
+    unsigned* const lo = L.hist;
+    unsigned* const mid = L.hist + 256 * 9;
+    unsigned* const hi = L.hist + 256 * 9 + 2048;
+    constexpr unsigned MID0 = 256u, MID1 = 2304u;
+    for (int i = tid; i < 512 * 9; i += NT) L.hist[i] = 0;
+    __syncthreads();
+    unsigned n1 = 0, nbig = 0;
+    unsigned long long sum = 0;
+    double isum = 0;
+    int mx = 0, mn = 0x7fffffff;
+    const int rep8 = lane & 7;
+    auto take = [&](int v) {
+        const unsigned u = (unsigned)v;
+        if (u - 1u < MID1 - 1u) {                                 // 1 <= v < 2304
+            if (u == 1u) ++n1;
+            else atomicAdd(u < MID0 ? &lo[u * 9 + rep8] : &mid[u - MID0], 1u);
+        } else {
+            ++nbig;
+            sum += (unsigned long long)(long long)v;
+            const double d = (double)v;
+            double q = (double)__builtin_amdgcn_rcpf((float)v);      // 1 / v: fp32 reciprocal + two Newton steps in fp64
+            q = q * (2.0 - d * q);
+            q = q * (2.0 - d * q);
+            isum += q;
+            mx = max(mx, v); mn = min(mn, v);
+            atomicAdd(&hi[min(u >> 8, 255u)], 1u);
+        }
+    };
+    // The counts were last touched by the other workgroups' device-scope atomics (performed at the memory side: the XCDs' L2s are not
+    // coherent with each other) and nobody has read them with plain loads during this launch, so after the caller's acquire fence (an
+    // L2 invalidate of this XCD, no write-back) plain 16-byte loads fetch them from memory.
+    const bool vec = ((((uintptr_t)r) | ((uintptr_t)ranks_out)) & 15) == 0;
+    const int n4 = vec ? n >> 2 : 0;
+    // batches of two 16-byte loads per lane (the launch must stay within 80 VGPRs), the NEXT batch requested before the current one is consumed
+    auto each = [&](auto&& f) {
+        constexpr int B = 2;
+        const int nb = n4 / (B * NT);                             // full batches
+        int4 cur[B], nxt[B];
+        if (nb > 0) {
+#pragma unroll
+            for (int u = 0; u < B; ++u) cur[u] = ((const int4*)r)[tid + u * NT];
+        }
+        for (int b = 0; b < nb; ++b) {
+            const int i4 = b * B * NT + tid;
+            if (b + 1 < nb) {
+#pragma unroll
+                for (int u = 0; u < B; ++u) nxt[u] = ((const int4*)r)[i4 + (B + u) * NT];
+            }
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const int i = 4 * (i4 + u * NT);
+                f(i, cur[u].x + base); f(i + 1, cur[u].y + base); f(i + 2, cur[u].z + base); f(i + 3, cur[u].w + base);
+            }
+#pragma unroll
+            for (int u = 0; u < B; ++u) cur[u] = nxt[u];
+        }
+        for (int i4 = nb * B * NT + tid; i4 < n4; i4 += NT) {
+            const int4 q = ((const int4*)r)[i4];
+            f(4 * i4, q.x + base); f(4 * i4 + 1, q.y + base); f(4 * i4 + 2, q.z + base); f(4 * i4 + 3, q.w + base);
+        }
+        for (int i = 4 * n4 + tid; i < n; i += NT) f(i, r[i] + base);
+    };
+    each([&](int i, int v) {
+        if (ranks_out) ranks_out[i] = v;           // (the four stores of a 16-byte group are merged by the compiler: consecutive i)
+        take(v);
+    });
+    __syncthreads();                                              // (every wave's histogram updates are in)
+    // lo: the replicas of bin tid -> one word; the sums over the bins: thread tid takes lo bin tid and mid bins 8 tid .. 8 tid + 7
+    unsigned own_lo = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) own_lo += lo[tid * 9 + q];
+    unsigned msum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned c = mid[8 * tid + q], v = MID0 + 8u * (unsigned)tid + (unsigned)q;
+        msum += c;
+        sum += (unsigned long long)c * v;
+        if (c) isum += (double)c / (double)v;
+    }
+    // (32 consecutive threads hold one 256-rank block of mid[]: its total is what hi[1 + tid / 32] lacks)
+    unsigned blk = msum;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) blk += __shfl_xor(blk, o);
+    unsigned c5 = 0, c10 = 0;
+    if (tid == 1) own_lo = 0;                                     // (lo[1] is n1, added below)
+    if (tid >= 2) {
+        c5 = tid <= 5 ? own_lo : 0u; c10 = tid <= 10 ? own_lo : 0u;
+        sum += (unsigned long long)own_lo * (unsigned)tid;
+        if (own_lo) isum += (double)own_lo / (double)tid;
+    }
+    unsigned nmid = msum;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        n1 += __shfl_xor(n1, o); nbig += __shfl_xor(nbig, o); nmid += __shfl_xor(nmid, o); sum += __shfl_xor(sum, o);
+        c5 += __shfl_xor(c5, o); c10 += __shfl_xor(c10, o);
+        isum += __shfl_xor(isum, o);
+        mx = max(mx, __shfl_xor(mx, o)); mn = min(mn, __shfl_xor(mn, o));
+    }
+    if (lane == 0) {
+        L.shl[wave][0] = n1 | ((unsigned long long)nbig << 32); L.shl[wave][1] = c5 | ((unsigned long long)c10 << 32);
+        L.shl[wave][2] = nmid; L.shl[wave][3] = sum;
+        L.shd[wave] = isum;
+        L.shm[wave][0] = mx; L.shm[wave][1] = mn;
+    }
+    __syncthreads();                                              // (all replicas read: lo[] is re-used as the compact histograms)
+    // compact layout from here on: L.hist[0..255] = lo, L.hist[256..511] = hi (mid[] stays where it is, beyond 256 * 9)
+    L.hist[tid] = own_lo;
+    {
+        const unsigned h = hi[tid];
+        __syncthreads();                                          // (hi[] read before L.hist[256 + tid] is written: the regions do not overlap, but keep the order explicit)
+        L.hist[256 + tid] = h;
+    }
+    __syncthreads();
+    if ((tid & 31) == 0) L.hist[256 + 1 + tid / 32] += blk;       // hi[1..8] += the mid blocks
+    n1 = nbig = nmid = c5 = c10 = 0; sum = 0; isum = 0; mx = 0; mn = 0x7fffffff;
+    for (int w = 0; w < NT / 64; ++w) {
+        n1 += (unsigned)L.shl[w][0]; nbig += (unsigned)(L.shl[w][0] >> 32); c5 += (unsigned)L.shl[w][1]; c10 += (unsigned)(L.shl[w][1] >> 32);
+        nmid += (unsigned)L.shl[w][2]; sum += L.shl[w][3]; isum += L.shd[w];
+        mx = max(mx, L.shm[w][0]); mn = min(mn, L.shm[w][1]);
+    }
+    sum += n1;
+    isum += (double)n1;
+    c5 += n1; c10 += n1;
+    __syncthreads();
+    if (tid == 0) { L.hist[1] = n1; L.hist[256] = (unsigned)n - nbig - nmid; }      // lo[1] and hi[0] = #{v < 256} were counted in registers
+    __syncthreads();
+    if (n > 0 && mn < 1) {                                        // invalid input: flag + NaN metrics
+        if (tid < 7) { out8[tid] = __builtin_nan(""); if (host8) host8[tid] = __builtin_nan(""); }
+        if (tid == 7) { out8[7] = 1.0; if (host8) host8[7] = 1.0; }
+        return;
+    }
+    if (nbig == 0) mx = (int)MID1 - 1;                            // (only the general select below reads mx, and only for ranks >= 65,280)
+    const int k = n / 2;                                          // k-th smallest, 0-based
+    auto select_bin = [&](int own, int less) {
+        int inc = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) L.wsum[wave] = inc;
+        __syncthreads();
+        int before = less + inc - own;
+        for (int w = 0; w < wave; ++w) before += L.wsum[w];
+        if (before <= k && k < before + own) { L.sel[0] = tid; L.sel[1] = before; }     // exactly one thread
+        __syncthreads();
+    };
+    unsigned prefix = 0, mask = 0;
+    int less = 0, shift, below = 0;
+    bool below_known = false;
+    const int in_lo = (int)L.hist[256];                           // hi[0] = #{v < 256}
+    if (k < in_lo) {
+        select_bin((int)L.hist[tid], 0);
+        prefix = (unsigned)L.sel[0]; less = L.sel[1];
+        mask = 0xffffffffu;
+        shift = -8;
+        for (int b = (int)prefix - 1; b >= 1; --b)
+            if (L.hist[b]) { below = b; break; }
+        below_known = true;
+    } else {
+        select_bin((int)L.hist[256 + tid], 0);
+        const int top = L.sel[0];
+        if (top >= 1 && top <= 8) {
+            // the median's 256-rank block lies inside mid[]: its low byte comes out of those bins, no pass over the ranks
+            less = L.sel[1];
+            select_bin((int)mid[256 * (top - 1) + tid], less);
+            prefix = ((unsigned)top << 8) | (unsigned)L.sel[0]; less = L.sel[1];
+            mask = 0xffffffffu;
+            shift = -8;
+        } else if (top < 255) { prefix = (unsigned)top << 8; less = L.sel[1]; mask = 0xffffff00u; shift = 0; }
+        else shift = ((32 - __clz(mx | 1) + 7) / 8 - 1) * 8;
+    }
+    for (; shift >= 0; shift -= 8) {
+        __syncthreads();
+        for (int i = tid; i < 256 * 9; i += NT) L.hist[i] = 0;
+        __syncthreads();
+        each([&](int, int vi) {
+            const unsigned v = (unsigned)vi;
+            if ((v & mask) == prefix) atomicAdd(&L.hist[((v >> shift) & 255u) * 9 + rep8], 1u);
+        });
+        __syncthreads();
+        int own = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) own += (int)L.hist[tid * 9 + q];
+        select_bin(own, less);
+        prefix |= (unsigned)L.sel[0] << shift;
+        mask |= 255u << shift;
+        less = L.sel[1];
+    }
+    const int med_lo = (int)prefix;
+    double med = med_lo;
+    if (n > 0 && (n & 1) == 0 && less >= k) {
+        if (!below_known) {
+            each([&](int, int v) {
+                if (v < med_lo) below = max(below, v);
+            });
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) below = max(below, __shfl_xor(below, o));
+            __syncthreads();
+            if (lane == 0) L.shm[wave][0] = below;
+            __syncthreads();
+            below = 0;
+            for (int w = 0; w < NT / 64; ++w) below = max(below, L.shm[w][0]);
+        }
+        med = 0.5 * (med + (double)below);
+    }
+    if (tid == 0) {
+        const double dn = (double)n;
+        double o[8] = {100.0 * ((double)n1 / dn), 100.0 * ((double)c5 / dn), 100.0 * ((double)c10 / dn), floor(med), (double)sum / dn,
+                       isum / dn, isum / dn, 0.0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { out8[i] = o[i]; if (host8) host8[i] = o[i]; }       // (visible to the host when the launch completes)
+    }
+}
+
 // ---- the strip kernel's list (sim_strip.hip): header {chunks taken from the pool, overflow flag, NW | 1 << 31, NCH} | NCH per-chunk
 // entry counts (rounded up to 4 words) | NCH chunks of STRIP_CHUNK entries of STRIP_ENTRY_WORDS words.  Chunks 0 .. NW - 1 belong to
 // the GEMM's wavefronts, chunks NW .. NW + taken - 1 were taken from the pool; the first count[c] entries of chunk c are valid.
@@ -425,18 +679,61 @@ __device__ __forceinline__ void resolve_groups(const float* __restrict__ Et, con
 // exact score, nudged by one ulp where rounding to fp32 would hide a strict inequality, so that ranks recounted from S
 // (laff_rank_count) equal the ranks produced here.  More pairs than the list holds: overflow flag + count[0] poisoned with -(2^26) (rank < 1 trips
 // the error flag of laff_rank_metrics*).
-__global__ __launch_bounds__(256) void rank_resolve_kernel(const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d,
-                                                           const double* __restrict__ s_gt64, int* __restrict__ count,
-                                                           float* __restrict__ S, long lds, unsigned* __restrict__ pairs,
-                                                           unsigned pair_cap) {
+__device__ __forceinline__ void resolve_pairs(const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d,
+                                              const double* __restrict__ s_gt64, int* __restrict__ count, float* __restrict__ S,
+                                              long lds, unsigned* __restrict__ pairs, unsigned pair_cap,
+                                              unsigned (*queue)[RESOLVE_QCAP][2]);
+
+// (six wavefronts per SIMD = the launch's 6 x CUs workgroups in one resident round: at most 80 VGPRs)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void rank_resolve_kernel(
+    const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d, const double* __restrict__ s_gt64, int* __restrict__ count,
+    float* __restrict__ S, long lds, unsigned* __restrict__ pairs, unsigned pair_cap, MetricsTail mt) {
+    __shared__ __attribute__((aligned(16))) unsigned char pool[RESOLVE_POOL_BYTES];      // the pair queues, then the metrics tail's state
+    unsigned (*queue)[RESOLVE_QCAP][2] = reinterpret_cast<unsigned (*)[RESOLVE_QCAP][2]>(pool);
+    if (pairs[2] & 0x80000000u)             // the strip kernel's list (sim_strip.hip): dumped groups of 16 raw accumulators
+        resolve_groups(Et, Ev, H, d, s_gt64, count, S, lds, pairs, pair_cap, queue);
+    else
+        resolve_pairs(Et, Ev, H, d, s_gt64, count, S, lds, pairs, pair_cap, queue);
+    if (mt.n <= 0) return;
+    // ---- metrics tail: every block releases its counts and draws a ticket; the last one sees all of them
+    // (No fences: a release / acquire pair at agent scope is an L2 write-back + invalidate per workgroup -- with 1,536 of them the launch
+    // took 0.34 ms instead of 0.06.  What the last block needs from the others are their count updates, device-scope atomics that have
+    // been performed once s_waitcnt vmcnt(0) returns; the ticket is a relaxed device-scope atomic issued after that wait, and the last
+    // block reads the counts behind the control dependency on its ticket and ONE acquire fence of its own.)
+    // Tickets in two levels (same-address device atomics serialise at ~10 ns each: 1,536 of them on one word, arriving together at the
+    // end of a balanced launch, cost 14 us): workgroup b draws from counter 1 + b % 32 (each on its own 256-byte line); the last
+    // arrival of a group draws from counter 0.
+    __shared__ unsigned s_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned g = blockIdx.x % RESOLVE_TICKET_GROUPS, gsz = (gridDim.x - g + RESOLVE_TICKET_GROUPS - 1u) / RESOLVE_TICKET_GROUPS;
+        const unsigned ngroups = gridDim.x < RESOLVE_TICKET_GROUPS ? gridDim.x : RESOLVE_TICKET_GROUPS;
+        unsigned* const tg = mt.ticket + 64u * (1u + g);
+        unsigned last = 0u;
+        if (__hip_atomic_fetch_add(tg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsz - 1u) {
+            __hip_atomic_store(tg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(mt.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u) {
+                __hip_atomic_store(mt.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1u;
+            }
+        }
+        s_ticket = last;
+    }
+    __syncthreads();
+    if (!s_ticket) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // one L2 invalidate in one workgroup (no write-back)
+    metrics_single_block<256>(count, mt.n, mt.base, mt.ranks_out, mt.out8, mt.host8, *reinterpret_cast<MetricsLds*>(pool));
+}
+
+// the tiled kernel's list: header {n_overflow, overflow flag, A, chunk}, A slots in per-wavefront segments, then the overflow pairs
+__device__ __forceinline__ void resolve_pairs(const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d,
+                                              const double* __restrict__ s_gt64, int* __restrict__ count, float* __restrict__ S,
+                                              long lds, unsigned* __restrict__ pairs, unsigned pair_cap,
+                                              unsigned (*queue)[RESOLVE_QCAP][2]) {
     const int sl = threadIdx.x & (RG - 1);
     const long K = (long)H * d;
     constexpr unsigned QCAP = RESOLVE_QCAP;
-    __shared__ unsigned queue[4][QCAP][2];
-    if (pairs[2] & 0x80000000u) {           // the strip kernel's list (sim_strip.hip): dumped groups of 16 raw accumulators
-        resolve_groups(Et, Ev, H, d, s_gt64, count, S, lds, pairs, pair_cap, queue);
-        return;
-    }
     const unsigned n_over = pairs[0], regA = pairs[2];
     const unsigned long long room = pair_cap > regA ? pair_cap - regA : 0u;
     if (n_over > room) {
@@ -642,12 +939,14 @@ hipError_t launch_rank_export(const double* s_gt64, int* count, float* S, int ld
 }
 
 hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv, int H, int d, const double* s_gt64, int* count,
-                               float* S, int lds, unsigned* pairs, unsigned pair_cap, hipStream_t st) {
+                               float* S, int lds, unsigned* pairs, unsigned pair_cap, hipStream_t st, int metrics_n, int base,
+                               int* ranks_out, double* out8, double* host8, unsigned* ticket) {
     (void)Nt; (void)Nv;
-    // one resident round: 16 KiB of LDS and ~70 VGPRs per block admit 7 blocks per CU; 6 x CUs leaves a margin (a second, sparse
+    // one resident round: ~19 KiB of LDS and ~70 VGPRs per block admit 7 blocks per CU; 6 x CUs leaves a margin (a second, sparse
     // round of the 2,048-block grid doubled this launch's time)
+    MetricsTail mt{metrics_n, base, ranks_out, out8, host8, ticket};
     hipLaunchKernelGGL(rank_resolve_kernel, dim3((unsigned)(6 * g_num_cus)), dim3(256), 0, st, Et, Ev, H, d, s_gt64, count, S, (long)lds, pairs,
-                       pair_cap);
+                       pair_cap, mt);
     return hipGetLastError();
 }
 
@@ -669,7 +968,9 @@ struct MetricsPartial { unsigned long long c1, c5, c10, sum; double isum; int mx
 static_assert(sizeof(MetricsPartial) == 64, "scratch layout");
 // scratch words: {ticket, 3 x pad} | lo[256] | hi[256] | pad to 4 KiB | MS_GMAX partials
 constexpr size_t MS_BYTES = 4096 + (size_t)MS_GMAX * sizeof(MetricsPartial);
-size_t rank_metrics_scratch_bytes() { return MS_BYTES; }
+// (+ the ticket lines of laff_rank_resolve_metrics behind it: the partials above are not left zero)
+size_t rank_metrics_scratch_bytes() { return MS_BYTES + ((RESOLVE_TICKET_BYTES + 4095) & ~(size_t)4095); }
+size_t rank_resolve_ticket_offset() { return MS_BYTES; }
 
 __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, int base, int* __restrict__ ranks_out,
                                                             double* __restrict__ out7, double* __restrict__ err,

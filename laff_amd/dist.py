@@ -241,6 +241,14 @@ class HipBackend:
         ops.rank_resolve(st, S)
         return S, st.count
 
+    def sim_ranked_finish(self, st, want_scores=True, out_pinned=None):
+        """sim_ranked + finish with the metrics computed by the resolve launch itself (laff_rank_resolve_metrics: nothing -- no
+        all-reduce of the counts -- comes between them on a single rank).  Returns (S, count, ranks, metrics or None)."""
+        S = ops.sim_gemm_banded(st, want_scores)
+        ranks = torch.empty_like(st.count)
+        metrics = ops.rank_resolve_metrics(st, S, out_pinned, base=1, ranks_out=ranks)
+        return S, st.count, ranks, metrics
+
     def finish(self, count, out_pinned=None):
         """ranks = count + 1 and the 7 metrics in one launch; returns (ranks, metrics or None when out_pinned is given).
         With out_pinned the caller checks out_pinned[7] (error flag) after its stream sync: check_metrics_flag()."""
@@ -311,6 +319,11 @@ def default_pair_bucket_cap(Nt, world):
     """Slots of one (sender, owner) bucket of 'video16''s pair all-to-all: the even share of 128 pairs per text (the headroom of
     ops.default_pair_cap: C4 lists 2.4 pairs per text, chance-level scores as in C3 ~30), at least 4096, a multiple of 4."""
     return max(4096, (128 * int(Nt) // max(world * world, 1) + 3) & ~3)
+
+
+def _fused_tail_enabled():
+    import os
+    return os.environ.get('LAFF_FUSED_TAIL', '1') != '0'
 
 
 def _flat_rows(E):
@@ -419,6 +432,17 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
         if comm:
             cx.all_reduce(compute.s_gt_of(st), 'max')
             mark('allreduce_s_gt')
+        metrics = None
+        fused_tail = (not comm and hasattr(compute, 'sim_ranked_finish') and (metrics_out is not None or want_metrics) and
+                      _fused_tail_enabled())
+        if fused_tail:
+            # one rank: GEMM, then ONE launch that re-scores the listed pairs and ends with the ranks + metrics
+            S_local, count, ranks, metrics = run('sim_finish' + finish_tag, lambda: compute.sim_ranked_finish(st, want_scores, metrics_out))
+            mark('sim_gemm')
+            mark('rank')
+            mark('metrics')
+            return {'S_local': S_local, 'col0': v0, 'ranks': ranks, 'metrics': metrics, 'vis_emb': vis_emb, 'txt_emb': txt_emb,
+                    'rank_state': st}
         S_local, count = run('sim', lambda: compute.sim_ranked(st, want_scores))
         mark('sim_gemm')
         if comm:
@@ -427,7 +451,6 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
             cx.all_reduce(count, 'sum')
             mark('allreduce_count')
 
-        metrics = None
         if hasattr(compute, 'finish') and (metrics_out is not None or want_metrics):
             # one launch: ranks = count + 1 and the metrics (no host sync when metrics_out is given)
             if metrics_out is not None:

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import (ACT, ATT_JUST_AVERAGE, ATT_L2NORM_EACH_HEAD, ATT_MUL, ATT_NO_SPLIT_HEAD, ATT_WITH_AVE, PREC,
                    FcProblem, FcSplitProblem, FcStripProblem, Plane, check, FcFusedProblem, RankSide)
 
-__all__ = ['rank_prepare', 'rank_prepare_text', 'rank_band_video', 'rank_export_pairs', 'rank_resolve_list', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'topk_from_operands', 'alloc_scores', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'fc_strip_pack', 'fc_strip_eligible', 'fc_act_bn_strip_grouped', 'StripWeights', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts', 'FusedPrepare', 'fused_prepare_eligible',
+__all__ = ['rank_resolve_metrics', 'rank_prepare', 'rank_prepare_text', 'rank_band_video', 'rank_export_pairs', 'rank_resolve_list', 'sim_gemm_banded', 'rank_resolve', 'exact_ranks', 'RankState', 'topk_rows', 'topk_from_operands', 'alloc_scores', 'frame_fuse_grouped', 'fc_act_bn_fused_grouped', 'fused_split_eligible', 'fc_strip_pack', 'fc_strip_eligible', 'fc_act_bn_strip_grouped', 'StripWeights', 'margin_loss', 'fc_gather_act_bn', 'fc_act_bn', 'fc_act_bn_grouped', 'fc_act_bn_split_grouped', 'split_rows', 'row_dot_gt', 'rank_metrics_async', 'fuse', 'frame_fuse', 'pack_rows', 'sim_gemm', 'gather_gt', 'rank_count', 'v2t_count', 'v2t_count_exact', 'reset_contexts', 'FusedPrepare', 'fused_prepare_eligible',
            'rank_metrics', 'attention_flags', 'PREC', 'default_prescale']
 
 _ctx = {}
@@ -883,6 +883,33 @@ def rank_resolve(st, S=None):
     _call('rank_resolve', lib.laff_rank_resolve, h, _ptr(st.Et), _ptr(st.Ev), Nt, st.Ev.shape[0], H, d, _ptr(st.s_gt64), _ptr(st.count),
           _ptr(S), lds, _ptr(st.pairs), st.pair_cap)
     return st.count
+
+
+def rank_resolve_metrics(st, S=None, out_pinned=None, base=1, ranks_out=None):
+    """laff_rank_resolve + the rank metrics in ONE launch (laff_rank_resolve_metrics): the resolve workgroup that finishes last turns
+    the final counts into ranks (ranks_out <- count + base) and the seven metrics.
+    out_pinned None: synchronises, returns the 7-tuple (RuntimeError if a rank < 1 was flagged: overflowed pair list).
+    out_pinned (pinned float64 tensor of >= 8): no sync, capturable; the device writes the 8 doubles into it directly; returns None."""
+    lds = 0
+    if S is not None:
+        S, lds = _rows(S, 'S')
+    Nt, H, d = st.Et.shape
+    lib, h = _context(st.Et.device)
+    if ('metrics', h.value) not in _ctx:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('call ops.ctx_prepare_metrics(device) before capturing a graph (it allocates scratch)')
+        ctx_prepare_metrics(st.Et.device)
+    ro = _ranks_out(st.count, ranks_out)
+    if out_pinned is None:
+        out = (C.c_double * 8)()
+        _call('rank_resolve', lib.laff_rank_resolve_metrics, h, _ptr(st.Et), _ptr(st.Ev), Nt, st.Ev.shape[0], H, d, _ptr(st.s_gt64),
+              _ptr(st.count), _ptr(S), lds, _ptr(st.pairs), st.pair_cap, int(base), _ptr(ro), out, 1)
+        return tuple(out)[:7]
+    if out_pinned.dtype != torch.float64 or out_pinned.numel() < 8 or not out_pinned.is_pinned():
+        raise ValueError('out_pinned must be a pinned float64 tensor of >= 8 elements')
+    _call('rank_resolve', lib.laff_rank_resolve_metrics, h, _ptr(st.Et), _ptr(st.Ev), Nt, st.Ev.shape[0], H, d, _ptr(st.s_gt64),
+          _ptr(st.count), _ptr(S), lds, _ptr(st.pairs), st.pair_cap, int(base), _ptr(ro), C.c_void_p(out_pinned.data_ptr()), 0)
+    return None
 
 
 def exact_ranks(Et, Ev, T, V, gt_col, want_scores=True, col0=0, pair_cap=None):

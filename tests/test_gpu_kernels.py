@@ -881,3 +881,84 @@ def test_c_abi_collectives_on_a_one_rank_group():
         assert lib.laff_allgather_rows(comm, None, None, 16) != 0 and b'null buffer' in lib.laff_last_error()
     finally:
         _lib.check(lib.laff_comm_destroy(comm))
+
+
+def _empty_list_state(count):
+    """A RankState whose pair list is empty (tiled format: header {0, 0, 0, 4}): laff_rank_resolve_metrics then reduces to the metrics
+    of count + base -- the tail of the fused launch on arbitrary rank distributions."""
+    from laff_amd import ops
+    n = count.numel()
+    d = torch.device(DEV)
+    Et = torch.zeros((n, 1, 4), device=d)
+    Ev = torch.zeros((1, 1, 4), device=d)
+    pairs = torch.zeros(4 + 2 * 8, dtype=torch.int32, device=d)
+    pairs[3] = 4
+    return ops.RankState(Et, Ev, None, None, 1, None, 0, torch.zeros(n, dtype=torch.float64, device=d), None, None, count, pairs, 8)
+
+
+def test_resolve_metrics_tail_on_the_median_cases():
+    """The metrics computed by the last workgroup of the resolve launch (laff_rank_resolve_metrics) on the rank distributions that
+    exercise every median path of the stand-alone kernel, synchronous and through a pinned buffer, ranks_out = count + base; a rank < 1
+    is flagged both ways and leaves the ticket clean for the next launch."""
+    from laff_amd import ops
+    g = rnd(777)
+    cases = [np.array([3, 3, 7, 9], np.int32), np.array([1, 1, 300, 400], np.int32), np.array([255, 256], np.int32),
+             np.array([256, 255, 255, 256], np.int32), np.array([65279, 65280], np.int32), np.array([70000, 65279, 1, 65281], np.int32),
+             np.array([511, 512, 512, 511], np.int32), np.array([5], np.int32), np.array([2 ** 31 - 1, 1], np.int32),
+             g.integers(1, 200, 40000).astype(np.int32), g.integers(1, 200, 40001).astype(np.int32),
+             g.integers(250, 262, 5000).astype(np.int32), g.integers(65270, 65290, 5003).astype(np.int32),
+             g.integers(1, 50000, 300000).astype(np.int32), g.integers(1, 100, 1 << 19).astype(np.int32),
+             np.concatenate([np.ones(20000, np.int32), g.integers(1, 3000, 20001).astype(np.int32)])]
+    pinned = torch.zeros(8, dtype=torch.float64).pin_memory()
+    for r in cases:
+        for base in (1, 0):
+            count = dev(r - base, torch.int32)
+            st = _empty_list_state(count)
+            ranks = torch.empty_like(count)
+            got = ops.rank_resolve_metrics(st, None, None, base=base, ranks_out=ranks)
+            np.testing.assert_allclose(got, _metrics_numpy(r), rtol=1e-13, atol=0, err_msg=str(r[:8]))
+            assert np.array_equal(ranks.cpu().numpy(), r)
+            pinned.fill_(-1.0)
+            assert ops.rank_resolve_metrics(st, None, pinned, base=base) is None
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(pinned[:7].numpy(), _metrics_numpy(r), rtol=1e-13, atol=0)
+            assert pinned[7].item() == 0.0
+        bad = r.copy(); bad[len(bad) // 2] = 0
+        st = _empty_list_state(dev(bad - 1, torch.int32))
+        with pytest.raises(RuntimeError):
+            ops.rank_resolve_metrics(st)
+        ops.rank_resolve_metrics(st, None, pinned)
+        torch.cuda.synchronize()
+        assert pinned[7].item() == 1.0 and np.isnan(pinned[0].item())
+
+
+@pytest.mark.parametrize('name,prec', [('tiny', 'fp16'), ('c2_10kx3k', 'fp16'), ('c2_10kx3k', 'bf16'), ('c4_40kx10k', 'fp16')])
+def test_fused_tail_equals_resolve_then_metrics(name, prec, monkeypatch):
+    """evaluate_sharded on one rank: GEMM + laff_rank_resolve_metrics (default) against GEMM + laff_rank_resolve + laff_rank_metrics
+    (LAFF_FUSED_TAIL=0): the same ranks, the same patched score matrix, metrics equal to rounding -- both list formats (the strip
+    kernel's dumps at 40k x 10k, the tiled kernel's pairs below), eager and replayed from a captured graph."""
+    from laff_amd import synth
+    from laff_amd.dist import HipBackend, check_metrics_flag, evaluate_sharded
+    Nt, Nv, H, d, _ = synth.WORKLOADS[name]
+    devc = torch.device(DEV)
+    model = synth.build_model(H, d, devc)
+    vis, txt, gt, _ = synth.make_features(Nt, Nv, devc)
+    be = HipBackend(model, prec)
+    monkeypatch.setenv('LAFF_FUSED_TAIL', '0')
+    ref = evaluate_sharded(be, vis, txt, gt, Nt, Nv, H)
+    monkeypatch.setenv('LAFF_FUSED_TAIL', '1')
+    got = evaluate_sharded(be, vis, txt, gt, Nt, Nv, H)
+    assert torch.equal(got['ranks'], ref['ranks'])
+    assert torch.equal(got['S_local'], ref['S_local'])
+    np.testing.assert_allclose(got['metrics'], ref['metrics'], rtol=1e-13, atol=0)
+    pinned = torch.zeros(8, dtype=torch.float64).pin_memory()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        out = evaluate_sharded(be, vis, txt, gt, Nt, Nv, H, metrics_out=pinned)
+    for _ in range(3):
+        pinned.fill_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        check_metrics_flag(pinned)
+        assert tuple(pinned[:7].tolist()) == tuple(got['metrics'])
+        assert torch.equal(out['ranks'], ref['ranks'])
