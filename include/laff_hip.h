@@ -401,7 +401,9 @@ int laff_topk_rows(laff_ctx* ctx, const float* S, int Nt, int Nv, int lds, int K
  * synchronises the stream. */
 int laff_rank_metrics(laff_ctx* ctx, const int* r, int Nq, int base, int* ranks_out, double out7[7]);
 /* Same, without synchronising: out8 is PINNED HOST memory (8 doubles: the 7 metrics + an error flag, 1.0 if a rank < 1 was
- * seen -- the 7 metrics are then NaN -- else 0.0); valid once the stream has been synchronised.  Capturable in a HIP graph. */
+ * seen -- the 7 metrics are then NaN -- else 0.0); valid once the stream has been synchronised.  Capturable in a HIP graph.
+ * The device writes a pinned (device-addressable) buffer directly from the kernel; any other host pointer gets a 64-byte copy queued
+ * behind the launch. */
 int laff_rank_metrics_async(laff_ctx* ctx, const int* r, int Nq, int base, int* ranks_out, double* out8_pinned_host);
 
 /* ---- e: the collectives of the sharded path for a host that is not Python (laff_amd/dist.py issues the same three through

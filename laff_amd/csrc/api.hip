@@ -994,9 +994,14 @@ int laff_rank_metrics_async(laff_ctx* ctx, const int* rank1, int Nq, int base, i
     if (int rc = metrics_buffers(ctx)) return rc;
     const size_t si = 1 + ctx->metrics_slot++ % (METRIC_SLOTS - 1);                                  // (slot 0: the synchronous call)
     double* slot = ctx->d_metrics + 8 * si;
+    // a pinned result buffer is addressable from the device: the finishing workgroup stores the 64 bytes there itself, no copy node
+    double* host8 = nullptr;
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, out8, 0) == hipSuccess && dp) host8 = (double*)dp;
+    else (void)hipGetLastError();
     HIP_TRY(laff::launch_rank_metrics(rank1, Nq, base, ranks_out, slot, slot + 7,
-                                      (unsigned*)(ctx->d_mscratch + si * laff::rank_metrics_scratch_bytes()), ctx->stream));
-    HIP_TRY(hipMemcpyAsync(out8, slot, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                                      (unsigned*)(ctx->d_mscratch + si * laff::rank_metrics_scratch_bytes()), ctx->stream, host8));
+    if (!host8) HIP_TRY(hipMemcpyAsync(out8, slot, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     return LAFF_OK;
 }
 

@@ -230,7 +230,9 @@ hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv,
 // scratch: rank_metrics_scratch_bytes() bytes, zero before the first launch (every launch leaves it zero); not shared by launches in flight
 size_t rank_metrics_scratch_bytes();
 size_t rank_resolve_ticket_offset();      // where, inside that scratch, the ticket lines of the fused resolve + metrics launch start
-hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, unsigned* scratch, hipStream_t st);
+// host8: the 8 result doubles also go to this device-addressable host buffer (null: none)
+hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, unsigned* scratch, hipStream_t st,
+                               double* host8 = nullptr);
 hipError_t launch_gather_gt(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, float* s_gt,
                             hipStream_t st);
 hipError_t launch_rank_count(const float* S, int Nt, int Nv, int lds, const int* gt_col, int col0, const float* s_gt,

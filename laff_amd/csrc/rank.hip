@@ -974,7 +974,7 @@ size_t rank_resolve_ticket_offset() { return MS_BYTES; }
 
 __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restrict__ r, int n, int base, int* __restrict__ ranks_out,
                                                             double* __restrict__ out7, double* __restrict__ err,
-                                                            unsigned* __restrict__ scratch) {
+                                                            unsigned* __restrict__ scratch, double* __restrict__ host8) {
     __shared__ double shd[16];
     __shared__ unsigned long long shl[16][4];
     __shared__ int shm[16][2];
@@ -1032,9 +1032,15 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
         }
     };
     block_sums();
+    // What the last block needs from the others travels as device-scope (memory-side) stores and atomics, has been performed once
+    // s_waitcnt vmcnt(0) returns, and is read back with device-scope loads: no fence anywhere (an agent-scope release / acquire is a
+    // write-back / invalidate of the XCD's whole L2 -- three of them per block were most of this launch's 20 us).
     if (tid == 0) {
-        MetricsPartial p{c1, c5, c10, sum, isum, mx, mn, {0, 0, 0, 0}};
-        parts[blockIdx.x] = p;
+        unsigned long long* q = (unsigned long long*)(parts + blockIdx.x);
+        const unsigned long long w[6] = {c1, c5, c10, sum, (unsigned long long)__double_as_longlong(isum),
+                                         (unsigned long long)(unsigned)mx | ((unsigned long long)(unsigned)mn << 32)};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) __hip_atomic_store(q + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid < 512) {
         unsigned t = 0;
@@ -1042,14 +1048,13 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
         for (int q = 0; q < 8; ++q) t += hist[tid * 9 + q];
         if (t) __hip_atomic_fetch_add(ghist + tid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_ticket = __hip_atomic_fetch_add(scratch, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(scratch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket != (unsigned)(G - 1)) return;
 
     // ---- the last block
-    __threadfence();
     {
         c1 = c5 = c10 = sum = 0; isum = 0; mx = 0; mn = 0x7fffffff;
         if (tid < G) {
@@ -1074,8 +1079,8 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     __syncthreads();
     mx = shm[0][0]; mn = shm[0][1];
     if (n > 0 && mn < 1) {                                        // invalid input: report (flag + NaN metrics), do not select
-        if (tid < 7) out7[tid] = __builtin_nan("");
-        if (tid == 0) err[0] = 1.0;
+        if (tid < 7) { out7[tid] = __builtin_nan(""); if (host8) host8[tid] = __builtin_nan(""); }
+        if (tid == 0) { err[0] = 1.0; if (host8) host8[7] = 1.0; }
         return;
     }
     const int k = n / 2;                                          // k-th smallest, 0-based
@@ -1168,15 +1173,19 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     }
     if (tid == 0) {
         const double dn = (double)n;
-        out7[0] = 100.0 * ((double)shl[0][0] / dn); out7[1] = 100.0 * ((double)shl[0][1] / dn); out7[2] = 100.0 * ((double)shl[0][2] / dn);
-        out7[3] = floor(med); out7[4] = (double)shl[0][3] / dn; out7[5] = shd[0] / dn; out7[6] = shd[0] / dn;
+        const double o[7] = {100.0 * ((double)shl[0][0] / dn), 100.0 * ((double)shl[0][1] / dn), 100.0 * ((double)shl[0][2] / dn), floor(med),
+                             (double)shl[0][3] / dn, shd[0] / dn, shd[0] / dn};
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { out7[i] = o[i]; if (host8) host8[i] = o[i]; }
         err[0] = 0.0;
+        if (host8) host8[7] = 0.0;                                // (device-addressable host memory: visible when the launch completes)
     }
 }
 
-hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, unsigned* scratch, hipStream_t st) {
+hipError_t launch_rank_metrics(const int* r, int n, int base, int* ranks_out, double* out7, double* err, unsigned* scratch, hipStream_t st,
+                               double* host8) {
     const int G = std::min(MS_GMAX, std::max(1, (n + 1023) / 1024));
-    hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)G), dim3(1024), 0, st, r, n, base, ranks_out, out7, err, scratch);
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)G), dim3(1024), 0, st, r, n, base, ranks_out, out7, err, scratch, host8);
     return hipGetLastError();
 }
 

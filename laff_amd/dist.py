@@ -321,9 +321,15 @@ def default_pair_bucket_cap(Nt, world):
     return max(4096, (128 * int(Nt) // max(world * world, 1) + 3) & ~3)
 
 
-def _fused_tail_enabled():
+def _fused_tail_enabled(Nt):
+    """laff_rank_resolve_metrics (ranks + metrics by the resolve launch's last workgroup) instead of laff_rank_resolve +
+    laff_rank_metrics_async: one CU reduces all Nt ranks, which beats a second launch up to ~16k queries (C2: 29 vs 31 + a gap us) and
+    loses beyond (C4, 40k: 97 vs 82 us).  LAFF_FUSED_TAIL = 0 / 1 forces the choice."""
     import os
-    return os.environ.get('LAFF_FUSED_TAIL', '1') != '0'
+    v = os.environ.get('LAFF_FUSED_TAIL')
+    if v is not None:
+        return v != '0'
+    return Nt <= 16384
 
 
 def _flat_rows(E):
@@ -434,7 +440,7 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
             mark('allreduce_s_gt')
         metrics = None
         fused_tail = (not comm and hasattr(compute, 'sim_ranked_finish') and (metrics_out is not None or want_metrics) and
-                      _fused_tail_enabled())
+                      _fused_tail_enabled(Nt))
         if fused_tail:
             # one rank: GEMM, then ONE launch that re-scores the listed pairs and ends with the ranks + metrics
             S_local, count, ranks, metrics = run('sim_finish' + finish_tag, lambda: compute.sim_ranked_finish(st, want_scores, metrics_out))
