@@ -640,9 +640,12 @@ __device__ __forceinline__ void resolve_groups(const float* __restrict__ Et, con
         qn = 0;
     };
     const unsigned long long trips = (slots + ngroups - 1) / ngroups;
+    const unsigned gpb = 256u / RG;                                          // groups per block
     for (unsigned long long it = 0; it < trips; ++it) {                      // wave-uniform trip count
         if (qn > QCAP - 64) drain();
-        const unsigned long long idx = it * ngroups + group;
+        // every block walks a CONTIGUOUS range of entries: the dumps of one GEMM wavefront share their 64 text rows, which then come
+        // out of this XCD's L2 the second time (entries dealt round-robin over the whole launch: 59.7 us at C4, this way 56.6)
+        const unsigned long long idx = ((unsigned long long)blockIdx.x * trips + it) * gpb + (group % gpb);
         const bool live = idx < slots && (unsigned)(idx % STRIP_CHUNK) < pairs[4 + (unsigned)(idx / STRIP_CHUNK)];
         bool inb = false;
         unsigned row = 0, col = 0;
