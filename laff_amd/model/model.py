@@ -72,30 +72,6 @@ def _loader_len(loader):
         return 1
 
 
-def _as_one_view(batches):
-    """Batches that are consecutive row slices of ONE tensor (a loader slicing a feature matrix that already sits in device or pinned
-    memory): the matrix itself as a view, no copy -- or None.  625 batches of four features are 2,500 slices: concatenating them costs
-    ~1.3 ms of host time at C4 and moves 410 MB on the device for nothing."""
-    first = batches[0]
-    if first.dim() < 1 or not first.is_contiguous() or first.layout != torch.strided:
-        return None
-    row = first[0].numel() * first.element_size() if first.shape[0] else 0
-    if row == 0:
-        return None
-    at, rows = first.data_ptr(), 0
-    base = first._base if first._base is not None else first
-    for b in batches:
-        if (b.data_ptr() != at or b.shape[1:] != first.shape[1:] or b.dtype != first.dtype or b.device != first.device or
-                not b.is_contiguous() or (b._base if b._base is not None else b) is not base):
-            return None
-        at += b.shape[0] * row
-        rows += b.shape[0]
-    try:
-        return torch.as_strided(base, (rows,) + tuple(first.shape[1:]), first.stride(), first.storage_offset())
-    except RuntimeError:
-        return None
-
-
 def coalesce_batches(batches):
     """Concatenate the batch dicts of a loader into one: tensors / arrays along dim 0, lists and tuples end to end, nested dicts
     key by key, None stays None.  Raises TypeError / ValueError / RuntimeError when the batches do not line up."""
@@ -111,8 +87,7 @@ def coalesce_batches(batches):
             raise ValueError('None mixed with values')
         return None
     if isinstance(first, torch.Tensor):
-        whole = _as_one_view(batches)
-        return whole if whole is not None else torch.cat(list(batches), dim=0)
+        return torch.cat(list(batches), dim=0)
     if isinstance(first, np.ndarray):
         return np.concatenate(list(batches), axis=0)
     if isinstance(first, (list, tuple)):

@@ -208,22 +208,3 @@ def test_gw_linear_decay_per_epoch():
 def test_evaluation_l2norm_golden(golden):
     g = golden('eval_cosine')
     np.testing.assert_allclose(evaluation.l2norm(g['q']), g['l2q'], rtol=0, atol=1e-6)
-
-
-def test_coalesce_batches_takes_consecutive_slices_as_one_view():
-    """Loader batches that are consecutive row slices of one tensor are handed on as a view of it (no copy); anything else -- a gap, a
-    clone, another tensor, a column slice -- is concatenated as before.  The values are the same either way."""
-    import torch
-    from laff_amd.model.model import _as_one_view, coalesce_batches
-    x = torch.arange(40.).reshape(10, 4)
-    v = coalesce_batches([x[0:3], x[3:6], x[6:10]])
-    assert v.data_ptr() == x.data_ptr() and torch.equal(v, x)
-    y = x[2:]
-    v = coalesce_batches([y[0:3], y[3:8]])
-    assert v.data_ptr() == y.data_ptr() and torch.equal(v, y)
-    z = torch.arange(40.).reshape(10, 4)
-    for bs in ([x[0:3], x[4:6]], [x[0:3], x[3:6].clone()], [x[0:3], z[3:6]], [x[:, :2][0:3], x[:, :2][3:6]]):
-        assert _as_one_view(bs) is None
-        assert torch.equal(coalesce_batches(bs), torch.cat(bs))
-    d = coalesce_batches([{'f': x[0:5], 'ids': ['a'] * 5, 'n': None}, {'f': x[5:10], 'ids': ['b'] * 5, 'n': None}])
-    assert d['f'].data_ptr() == x.data_ptr() and d['ids'] == ['a'] * 5 + ['b'] * 5 and d['n'] is None
