@@ -42,7 +42,7 @@ def main():
         w = sum(write[k]) / max(1, len(write[k]))
         kernels[k] = {'launches_seen': len(fetch[k]), 'fetch_reported_MB': round(f / 1e6, 1), 'fetch_corrected_MB': round(2 * f / 1e6, 1),
                       'write_MB': round(w / 1e6, 1)}
-    json.dump({'_comment': 'average bytes per launch over every launch of the kernel in `python3 bench.py --steps 5 --warmup 2 '
+    json.dump({'_comment': 'average bytes per launch over every launch of the kernel in `python3 bench.py --steps 20 --warmup 5 --profile-steps 5 '
                            '--no-cpu-baseline --no-extra-modes` (warm-up, graph replays and the eager profiling pass alike); FETCH_SIZE x2 per '
                            'MI355X_MICROARCH.md; made by tools/make_traffic.py from separate --pmc passes',
                'workload': 'c4_40kx10k', 'precision': 'fp16', 'fc_precision': 'fp16x3', 'src_sha': source_hash(), 'kernels': kernels},

@@ -5,11 +5,11 @@
 #   3. the un-profiled bench line                                     -> profiles/<tag>_bench_line.json
 # Counter passes never combine --pmc with a trace domain (MI355X_MICROARCH.md; the pool refuses that combination).
 set -e
-TAG=${1:-r4}
+TAG=${1:-r5}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT" "$ROOT/profiles"
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-modes"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --profile-steps 5 --no-cpu-baseline --no-extra-modes"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- $BENCH > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- $BENCH > "$OUT/fetch.log" 2>&1
@@ -28,5 +28,5 @@ cp $S/${TAG}_traffic.json profiles/${TAG}_traffic.json          # bench.py reads
 python3 tools/timeline.py "$OUT/trace" > $S/${TAG}_bench_timeline.txt || true
 cp "$OUT/trace/t_kernel_stats.csv" $S/${TAG}_bench_kernel_stats.csv
 grep '"metric"' "$OUT/trace.log" | tail -1 > $S/${TAG}_bench_line_under_rocprof.json || true   # the bench's own HIP-event durations in the traced run
-python3 bench.py > $S/${TAG}_bench_line.json 2> "$OUT/bench.err"
+python3 bench.py --steps 20 --warmup 5 > $S/${TAG}_bench_line.json 2> "$OUT/bench.err"
 tail -c 700 $S/${TAG}_bench_line.json
