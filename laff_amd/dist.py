@@ -115,6 +115,25 @@ class HipBackend:
             if fused is not None:
                 vl.rank_side = tl.rank_side = None
 
+    def embed_video_first(self, vis_feats, txt_feats):
+        """embed_both in two steps (retrieval.embed_split): all FC projections + the video fusion now; returns (vis_emb, finish) where
+        finish() launches the text fusion and returns txt_emb.  The video tower's operand is not emitted (its rows are gathered in
+        fp32 and packed behind the collective); the text tower's is."""
+        from .retrieval import embed_split
+        self._emit_packed(True)
+        try:
+            vis_emb, fin_t = embed_split(self.model, vis_feats, txt_feats)
+        finally:
+            self._emit_packed(False)
+
+        def finish():
+            self._emit_packed(True)
+            try:
+                return fin_t()
+            finally:
+                self._emit_packed(False)
+        return vis_emb, finish
+
     def fused_prepare(self, Nt, Nv, heads, gt, col0=0):
         """An ops.FusedPrepare when both towers end in a fuse launch that can carry laff_rank_prepare's work (one head of d <= 512,
         fp16 / bf16 operand emitted by the launch; LAFF_FUSED_PREPARE=0 turns it off), else None (separate rank_prepare launch)."""
@@ -502,25 +521,52 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
     if hasattr(compute, 'set_unpacked'):
         compute.set_unpacked('vis' if comm else None)
     with torch.no_grad():
-        def towers():
-            if hasattr(compute, 'embed_both'):
-                vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local)
-            else:
-                txt_emb, vis_emb = compute.embed_text(txt_feats_local), compute.embed_video(vis_feats_local)
-            T_local = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
-            if comm:
-                return txt_emb, vis_emb, T_local, None, _pad_rows(_flat_rows(vis_emb), vmax)
-            V_local = compute.pack(vis_emb, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack(vis_emb)
-            return txt_emb, vis_emb, T_local, V_local, None
-        txt_emb, vis_emb, T_local, V_local, send = run('towers_t', towers)
-        mark('towers')
-        if comm:
+        if comm and hasattr(compute, 'embed_video_first'):
+            # Every FC projection of both towers in one launch, the video fusion, then the video rows leave for the other ranks
+            # (asynchronously) while the text side is fused: the gather's first ~20-50 us (the text fusion of a 1/8 .. 1/2 shard) are off
+            # the critical path at no extra launch.
+            fin_box = [None]
+
+            def towers_a():
+                vis_emb, fin_box[0] = compute.embed_video_first(vis_feats_local, txt_feats_local)
+                return vis_emb, _pad_rows(_flat_rows(vis_emb), vmax)
+            vis_emb, send = run('towers_ta', towers_a)
+            mark('vis_tower')
             shape = (world * vmax, send.shape[1])
             if 'gathered_v' not in state or tuple(state['gathered_v'].shape) != shape:
                 state['gathered_v'] = torch.empty(shape, dtype=send.dtype, device=send.device)
             gathered = state['gathered_v']
-            cx.all_gather(gathered, send)
-        mark('all_gather_wait')
+            work = cx.all_gather(gathered, send, async_op=True)
+
+            def towers_b():
+                txt_emb = fin_box[0]()
+                return txt_emb, (compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb))
+            txt_emb, T_local = run('towers_tb', towers_b)
+            V_local = None
+            mark('towers')
+            if work is not None:
+                work.wait()
+            mark('all_gather_wait')
+        else:
+            def towers():
+                if hasattr(compute, 'embed_both'):
+                    vis_emb, txt_emb = compute.embed_both(vis_feats_local, txt_feats_local)
+                else:
+                    txt_emb, vis_emb = compute.embed_text(txt_feats_local), compute.embed_video(vis_feats_local)
+                T_local = compute.pack(txt_emb, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack(txt_emb)
+                if comm:
+                    return txt_emb, vis_emb, T_local, None, _pad_rows(_flat_rows(vis_emb), vmax)
+                V_local = compute.pack(vis_emb, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack(vis_emb)
+                return txt_emb, vis_emb, T_local, V_local, None
+            txt_emb, vis_emb, T_local, V_local, send = run('towers_t', towers)
+            mark('towers')
+            if comm:
+                shape = (world * vmax, send.shape[1])
+                if 'gathered_v' not in state or tuple(state['gathered_v'].shape) != shape:
+                    state['gathered_v'] = torch.empty(shape, dtype=send.dtype, device=send.device)
+                gathered = state['gathered_v']
+                cx.all_gather(gathered, send)
+            mark('all_gather_wait')
         # this rank's slice of the ground-truth columns lives in `state`: a captured phase reads it at a fixed address on every
         # replay, and it is refreshed from `gt` on every step (outside the captured phase) like the 'video' scheme reads gt live
         if 'gt_local' not in state or state['gt_local'].numel() != t1 - t0 or state['gt_local'].device != gt.device:

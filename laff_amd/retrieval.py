@@ -29,6 +29,24 @@ def embed(model, vis_feats, txt_feats):
     return fin_v(), fin_t()
 
 
+def embed_split(model, vis_feats, txt_feats):
+    """embed() in two steps: every FC projection of both towers (ONE grouped launch) and the VIDEO fusion now; returns (vis_emb, finish_text)
+    -- finish_text() launches the text fusion.  For callers that have something to start between the two (the sharded pass sends the
+    video rows to the other ranks while the text side is fused)."""
+    vis = dict(vis_feats)
+    frame_dict = {}
+    if 'mask_tensor' in vis:
+        frame_dict, vis = vis, {}
+    cap = dict(txt_feats)
+    cap.setdefault('caption', None)
+    pending = []
+    fin_v = model.vis_net.prepare(vis, frame_dict, pending)
+    fin_t = model.txt_net.prepare(cap, pending)
+    from .model.model import run_fc
+    run_fc(pending)
+    return fin_v(), fin_t
+
+
 def evaluate(model, vis_feats, txt_feats, gt, precision='fp16', write_scores=True, want_metrics=True, exact=True):
     """One pass of the hot path on one GPU.  gt: int32 (Nt,) device tensor of ground-truth video columns.
     write_scores=False skips materialising S (ranks only).
