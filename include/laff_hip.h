@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LAFF_ABI_VERSION 21
+#define LAFF_ABI_VERSION 22
 
 enum {
     LAFF_OK = 0,
@@ -305,6 +305,14 @@ int laff_match_ids(const char* txt_blob, size_t txt_bytes, int n_txt, const char
  *   sides = 2, video rows: band_v [((Nv + 3) & ~3) + ceil(Nv / 64)] (Et, T, gt_col, s_gt64, band_t untouched, may be NULL). */
 int laff_rank_prepare_part(laff_ctx* ctx, int sides, const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H,
                            int d, int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t, float* band_v,
+                           int* zero_count, unsigned* pairs);
+
+/* laff_rank_prepare that PRODUCES one or both GEMM operands on the way (emit: 1 = T, 2 = V, 3 = both): E16 = fp16 / bf16 (E * prescale),
+ * no re-normalisation -- what laff_pack_rows(normalize = 0) writes for rows that are unit-norm already (the towers' outputs; gathered
+ * embedding rows of a sharded pass, laff_amd/dist.py): one launch and one pass over those rows instead of two.  The operand not named in
+ * `emit` is read as in laff_rank_prepare.  Single-plane 16-bit precisions only (LAFF_E_UNSUPPORTED otherwise). */
+int laff_rank_prepare_emit(laff_ctx* ctx, int emit, const float* Et, const float* Ev, void* T, void* V, int Nt, int Nv, int H, int d,
+                           int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t, float* band_v,
                            int* zero_count, unsigned* pairs);
 
 /* The listed pairs of a video shard's laff_sim_gemm_banded, exported to the owners of the TEXT rows instead of re-scored here (the exact

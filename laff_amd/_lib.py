@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get('LAFF_HIP_LIB') or os.path.join(_HERE, 'lib', 'liblaff
 ACT = {None: 0, False: 0, '': 0, 'none': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
 ATT_WITH_AVE, ATT_MUL, ATT_L2NORM_EACH_HEAD, ATT_NO_SPLIT_HEAD, ATT_JUST_AVERAGE = 1, 2, 4, 8, 16
 PREC = {'fp32': 0, 'fp16': 1, 'bf16': 2, 'fp16x3': 3, 'bf16x3': 4}
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 class Plane(C.Structure):
@@ -89,6 +89,7 @@ SIGNATURES = {
     'laff_rank_prepare': (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P]),
     'laff_match_ids': (C.c_int, [C.c_char_p, C.c_size_t, _I, C.c_char_p, C.c_size_t, _I, _P]),
     'laff_rank_prepare_part': (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P]),
+    'laff_rank_prepare_emit': (C.c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P]),
     'laff_rank_export_pairs': (C.c_int, [_P, _P, _P, _P, _I, _I, _P, C.c_uint, _P, _I, _I, _P, C.c_uint, _P]),
     'laff_sim_gemm_banded': (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, C.c_uint]),
     'laff_rank_resolve': (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, C.c_uint]),

@@ -830,6 +830,25 @@ int laff_rank_prepare_part(laff_ctx* ctx, int sides, const float* Et, const floa
     return LAFF_OK;
 }
 
+int laff_rank_prepare_emit(laff_ctx* ctx, int emit, const float* Et, const float* Ev, void* T, void* V, int Nt, int Nv, int H, int d,
+                           int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t, float* band_v,
+                           int* zero_count, unsigned* pairs) {
+    CHECK_CTX(ctx);
+    if (emit < 1 || emit > 3) return fail(LAFF_E_ARG, "laff_rank_prepare_emit: emit must be 1 (T), 2 (V) or 3 (both)");
+    if (precision != LAFF_PREC_FP16 && precision != LAFF_PREC_BF16)
+        return fail(LAFF_E_UNSUPPORTED, "laff_rank_prepare_emit: single-plane 16-bit operands only (precision %d): call laff_pack_rows + laff_rank_prepare", precision);
+    if (Nt == 0 || Nv == 0) return LAFF_OK;
+    if (!Et || !Ev || !T || !V || !gt_col || !s_gt64 || !band_t || !band_v) return fail(LAFF_E_ARG, "laff_rank_prepare_emit: null argument");
+    if (Nt < 0 || Nv < 0 || H < 1 || d < 4 || (d & 3)) return fail(LAFF_E_SHAPE, "laff_rank_prepare_emit: need H >= 1, d %% 4 == 0 (Nt=%d Nv=%d H=%d d=%d)", Nt, Nv, H, d);
+    if (!(prescale > 0.0f)) return fail(LAFF_E_ARG, "laff_rank_prepare_emit: prescale must be positive");
+    if (!aligned16(Et) || !aligned16(Ev) || !aligned16(T) || !aligned16(V))
+        return fail(LAFF_E_ALIGN, "laff_rank_prepare_emit: embeddings and operands must be 16-byte aligned");
+    DeviceGuard g(ctx->device);
+    HIP_TRY(laff::launch_rank_prepare(Et, Ev, T, V, Nt, Nv, H, d, precision, prescale, gt_col, col0, s_gt64, band_t, band_v, zero_count,
+                                      pairs, 3, ctx->stream, emit));
+    return LAFF_OK;
+}
+
 int laff_rank_export_pairs(laff_ctx* ctx, const double* s_gt64, int* count, float* S, int lds, int Nv, unsigned* pairs, unsigned pair_cap,
                            const int* bounds, int world, int col0, unsigned* out, unsigned cap, unsigned* fill) {
     CHECK_CTX(ctx);

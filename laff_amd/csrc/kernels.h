@@ -219,7 +219,7 @@ hipError_t launch_row_dot_gt(const void* T, const void* V, int Nt, int Nv, int K
                              const int* gt_col, int col0, float* s_gt, int* zero_count, hipStream_t st);
 hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
                                int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t,
-                               float* band_v, int* zero_count, unsigned* pairs, int sides, hipStream_t st);
+                               float* band_v, int* zero_count, unsigned* pairs, int sides, hipStream_t st, int emit = 0);
 hipError_t launch_rank_export(const double* s_gt64, int* count, float* S, int lds, unsigned* pairs, unsigned pair_cap, const int* bounds,
                               int world, int col0, unsigned* out, unsigned cap, unsigned* fill, hipStream_t st);
 // metrics_n > 0: the block that finishes last also turns the counts into ranks (count + base -> ranks_out) and the seven metrics

@@ -201,9 +201,12 @@ __device__ __forceinline__ void load_operand4(const void* __restrict__ op, long 
 // xx - 2 xe / n + ee / n^2 per head with the three sums in fp64 (the terms cancel to ~1e-8 of their size; fp64 leaves 1e-16), and --
 // WITH_GT -- the exact cosine against the ground-truth row v in the same loop.  tt / vv / tv use exactly exact_cos()'s lane map, fma
 // order and reduction tree, so the value is bit-identical to what laff_rank_resolve computes for the same two rows.
-template <int PREC, bool WITH_GT>
+// EMIT (single-plane 16-bit formats): the operand row is PRODUCED here -- x = fp16 / bf16 (e * prescale), stored to `op` -- instead of read:
+// what laff_pack_rows(normalize = 0) would have written for the row (laff_rank_prepare_emit: one launch and one pass over gathered rows
+// instead of two).
+template <int PREC, bool WITH_GT, bool EMIT = false>
 __device__ __forceinline__ float row_pass(const float* __restrict__ e, const void* __restrict__ op, long row, long nrows, int H, int d,
-                                          double inv_prescale, int sl, const float* __restrict__ v, double* cos_out) {
+                                          double inv_prescale, int sl, const float* __restrict__ v, double* cos_out, float prescale = 1.0f) {
     const long K = (long)H * d;
     double q2 = 0.0, s = 0.0;
     for (int h = 0; h < H; ++h) {
@@ -213,7 +216,19 @@ __device__ __forceinline__ float row_pass(const float* __restrict__ e, const voi
         for (int c = sl * 4; c < d; c += RG * 4) {
             const float4 a = *(const float4*)(eh + c);
             float x[4];
-            load_operand4<PREC>(op, row * K + (long)h * d + c, nrows * K, x);
+            if constexpr (EMIT && (PREC == LAFF_PREC_FP16 || PREC == LAFF_PREC_BF16)) {
+                const float s4[4] = {a.x * prescale, a.y * prescale, a.z * prescale, a.w * prescale};
+                uint16_t b4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (PREC == LAFF_PREC_BF16) { const __bf16 t = (__bf16)s4[i]; x[i] = (float)t; __builtin_memcpy(&b4[i], &t, 2); }
+                    else { const _Float16 t = (_Float16)s4[i]; x[i] = (float)t; __builtin_memcpy(&b4[i], &t, 2); }
+                }
+                *(uint2*)((uint16_t*)const_cast<void*>(op) + row * K + (long)h * d + c) =
+                    make_uint2((unsigned)b4[0] | ((unsigned)b4[1] << 16), (unsigned)b4[2] | ((unsigned)b4[3] << 16));
+            } else {
+                load_operand4<PREC>(op, row * K + (long)h * d + c, nrows * K, x);
+            }
             const double ax = a.x, ay = a.y, az = a.z, aw = a.w;
             tt = fma(ax, ax, tt); tt = fma(ay, ay, tt); tt = fma(az, az, tt); tt = fma(aw, aw, tt);
             if constexpr (WITH_GT) {
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
                                                            int H, int d, float inv_prescale, float unit, float c_acc, const int* __restrict__ gt_col,
                                                            int col0, double* __restrict__ s_gt64, float* __restrict__ band_t,
                                                            float* __restrict__ band_v, int* __restrict__ zero_count,
-                                                           unsigned* __restrict__ pairs, long vblocks) {
+                                                           unsigned* __restrict__ pairs, long vblocks, int emit, float prescale) {
     __shared__ float blkmax[PREP_ROWS];
     const int sl = threadIdx.x & (RG - 1), grp = threadIdx.x / RG;
     const long K = (long)H * d;
@@ -264,7 +279,14 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
         const bool own = c >= 0 && c < Nv;
         double sg = -INFINITY;
         float q;
-        if (__builtin_amdgcn_ballot_w64(own) != 0ull) {            // wave-uniform: some group of this wavefront owns its column
+        if (emit & 1) {                                             // kernel-uniform: the text operand is produced here (every group writes
+            if (__builtin_amdgcn_ballot_w64(own) != 0ull) {        // its own row; idle groups shadow row Nt - 1 with the same values)
+                q = row_pass<PREC, true, true>(e, T, t, Nt, H, d, (double)inv_prescale, sl, Ev + (long)(own ? c : 0) * K, &sg, prescale);
+                if (!own) sg = -INFINITY;
+            } else {
+                q = row_pass<PREC, false, true>(e, T, t, Nt, H, d, (double)inv_prescale, sl, nullptr, nullptr, prescale);
+            }
+        } else if (__builtin_amdgcn_ballot_w64(own) != 0ull) {     // wave-uniform: some group of this wavefront owns its column
             q = row_pass<PREC, true>(e, T, t, Nt, H, d, (double)inv_prescale, sl, Ev + (long)(own ? c : 0) * K, &sg);
             if (!own) sg = -INFINITY;
         } else {
@@ -283,7 +305,8 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
             const long v0 = vb * PREP_VROWS + k * PREP_ROWS + grp;
             const bool ok = v0 < Nv;
             const long v = ok ? v0 : Nv - 1;
-            const float q = row_pass<PREC, false>(Ev + v * K, V, v, Nv, H, d, (double)inv_prescale, sl, nullptr, nullptr);
+            const float q = (emit & 2) ? row_pass<PREC, false, true>(Ev + v * K, V, v, Nv, H, d, (double)inv_prescale, sl, nullptr, nullptr, prescale)
+                                       : row_pass<PREC, false>(Ev + v * K, V, v, Nv, H, d, (double)inv_prescale, sl, nullptr, nullptr);
             const float b = q * rsqrt_h * 1.0001f;
             if (ok && sl == 0) band_v[v] = b;
             if (ok) mx = fmaxf(mx, b);
@@ -300,7 +323,7 @@ __global__ __launch_bounds__(256) void rank_prepare_kernel(const float* __restri
 
 hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, const void* V, int Nt, int Nv, int H, int d,
                                int precision, float prescale, const int* gt_col, int col0, double* s_gt64, float* band_t,
-                               float* band_v, int* zero_count, unsigned* pairs, int sides, hipStream_t st) {
+                               float* band_v, int* zero_count, unsigned* pairs, int sides, hipStream_t st, int emit) {
     // sides: 1 = the text rows (s_gt64, band_t, cleared count / list header), 2 = the video rows (band_v), 3 = both
     const long vblocks = (sides & 2) ? ((long)Nv + PREP_VROWS - 1) / PREP_VROWS : 0;
     const long grid = ((sides & 1) ? ((long)Nt + PREP_ROWS - 1) / PREP_ROWS : 0) + vblocks;
@@ -314,7 +337,7 @@ hipError_t launch_rank_prepare(const float* Et, const float* Ev, const void* T, 
     const float c_acc = (float)((double)H * d * (x3 ? 3.0 : 1.0) * 1.1920929e-7 + 9.5367432e-7 + (x3 ? 2.3841858e-7 : 0.0));
 #define LAFF_PREP(P, U)                                                                                                          \
     hipLaunchKernelGGL((rank_prepare_kernel<P>), dim3((unsigned)grid), dim3(256), 0, st, Et, Ev, T, V, Nt, Nv, H, d, inv, U, c_acc, gt_col, \
-                       col0, s_gt64, band_t, band_v, zero_count, pairs, vblocks)
+                       col0, s_gt64, band_t, band_v, zero_count, pairs, vblocks, emit, prescale)
     switch (precision) {
         case LAFF_PREC_FP32: LAFF_PREP(LAFF_PREC_FP32, 5.9604645e-8f); break;
         case LAFF_PREC_FP16: LAFF_PREP(LAFF_PREC_FP16, 4.8828125e-4f); break;

@@ -251,6 +251,18 @@ class HipBackend:
         """Exact ground-truth scores of the texts whose video is in [col0, col0 + Nv), error bands, cleared accumulators."""
         return ops.rank_prepare(Et, Ev, T, V, gt, col0)
 
+    def prepare_gathered(self, Et, Ev, T, V, gt, col0, layer):
+        """prepare() for a pass in which one side's rows have just been gathered (T or V None): their operand is produced by the
+        prepare launch itself instead of a pack_rows pass in front of it -- when the operand is what pack_gathered() would return
+        bit for bit (a single-plane 16-bit format made from unit-norm rows without re-normalising); else pack_gathered + prepare."""
+        if self.precision in ('fp16', 'bf16') and self._fused_pack(layer):
+            return ops.rank_prepare(Et, Ev, T, V, gt, col0, emit_precision=self.precision)
+        if T is None:
+            T = self.pack_gathered(Et, layer)
+        if V is None:
+            V = self.pack_gathered(Ev, layer)
+        return ops.rank_prepare(Et, Ev, T, V, gt, col0)
+
     def s_gt_of(self, st):
         return st.s_gt64
 
@@ -443,6 +455,8 @@ def evaluate_sharded(compute, vis_feats_local, txt_feats_local, gt, Nt, Nv, head
         def prep_phase():
             if comm:
                 Et = _compact(gathered, sizes, nmax, heads)
+                if hasattr(compute, 'prepare_gathered'):
+                    return compute.prepare_gathered(Et, vis_emb, None, V_local, gt, v0, compute.txt_layer())
                 T = compute.pack_gathered(Et, compute.txt_layer()) if hasattr(compute, 'txt_layer') else compute.pack_gathered(Et)
             elif hasattr(compute, 'embed_both'):
                 if fused_box[0] is not None:
@@ -577,10 +591,14 @@ def evaluate_sharded_by_text(compute, vis_feats_local, txt_feats_local, gt, Nt, 
         def rank_phase():
             if comm:
                 Ev = _compact(gathered, vsizes, vmax, heads)
-                V = compute.pack_gathered(Ev, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack_gathered(Ev)
+                V = None if hasattr(compute, 'prepare_gathered') else (
+                    compute.pack_gathered(Ev, compute.vis_layer()) if hasattr(compute, 'vis_layer') else compute.pack_gathered(Ev))
             else:
                 Ev, V = vis_emb, V_local
-            st = compute.prepare(txt_emb, Ev, T_local, V, gt_local, 0)
+            if V is None:
+                st = compute.prepare_gathered(txt_emb, Ev, T_local, None, gt_local, 0, compute.vis_layer())
+            else:
+                st = compute.prepare(txt_emb, Ev, T_local, V, gt_local, 0)
             S_local, count = compute.sim_ranked(st, want_scores)
             mine = (count + 1).to(torch.int32)
             if comm and mine.numel() != tmax:

@@ -751,13 +751,27 @@ class FusedPrepare:
                          self.count, self.pairs, self.pair_cap)
 
 
-def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None):
+def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None, emit_precision=None):
     """First launch of the exact-rank pipeline.  Et (Nt, H, d) / Ev (Nv, H, d): the fp32 embeddings; T / V: the Packed GEMM
     operands made from them; gt_col int32 (Nt,) ground-truth column of every text (global index; col0 = first column of this
-    video shard).  Returns a RankState."""
+    video shard).  Returns a RankState.
+    T or V None (with emit_precision 'fp16' | 'bf16', or the other operand's): that operand is PRODUCED by the launch from the
+    embedding rows -- E * prescale converted without re-normalising, what pack_rows(E, normalize=False) returns (laff_rank_prepare_emit);
+    it is in the returned state."""
     Et, Ev = _emb3(Et, 'Et'), _emb3(Ev, 'Ev')
     Nt, H, d = Et.shape
     Nv = Ev.shape[0]
+    emit = (1 if T is None else 0) | (2 if V is None else 0)
+    if emit:
+        have = T if T is not None else V
+        prec = emit_precision or (have.precision if have is not None else None)
+        if prec not in ('fp16', 'bf16'):
+            raise ValueError("rank_prepare can only produce single-plane 16-bit operands ('fp16' | 'bf16'), got %r" % prec)
+        ps = have.prescale if have is not None else default_prescale(prec)
+        if T is None:
+            T = Packed(torch.empty((max(Nt * H * d * 2, 16),), device=Et.device, dtype=torch.uint8), Nt, H * d, prec, ps)
+        if V is None:
+            V = Packed(torch.empty((max(Nv * H * d * 2, 16),), device=Et.device, dtype=torch.uint8), Nv, H * d, prec, ps)
     if tuple(Ev.shape[1:]) != (H, d) or T.N != Nt or V.N != Nv or T.K != H * d or V.K != H * d:
         raise ValueError('embeddings %s / %s do not match the operands (%d x %d, %d x %d)' % (tuple(Et.shape), tuple(Ev.shape), T.N, T.K, V.N, V.K))
     if T.precision != V.precision or T.prescale != V.prescale:
@@ -777,8 +791,12 @@ def rank_prepare(Et, Ev, T, V, gt_col, col0=0, pair_cap=None):
     count = torch.empty((Nt,), device=dev, dtype=torch.int32)
     pairs = torch.empty((4 + 2 * cap,), device=dev, dtype=torch.int32)
     lib, h = _context(dev)
-    _call('rank_prepare', lib.laff_rank_prepare, h, _ptr(Et), _ptr(Ev), _ptr(T.buf), _ptr(V.buf), Nt, Nv, H, d, PREC[T.precision],
-          float(T.prescale), _ptr(gt_col), int(col0), _ptr(s_gt64), _ptr(band_t), _ptr(band_v), _ptr(count), _ptr(pairs))
+    if emit:
+        _call('rank_prepare', lib.laff_rank_prepare_emit, h, emit, _ptr(Et), _ptr(Ev), _ptr(T.buf), _ptr(V.buf), Nt, Nv, H, d, PREC[T.precision],
+              float(T.prescale), _ptr(gt_col), int(col0), _ptr(s_gt64), _ptr(band_t), _ptr(band_v), _ptr(count), _ptr(pairs))
+    else:
+        _call('rank_prepare', lib.laff_rank_prepare, h, _ptr(Et), _ptr(Ev), _ptr(T.buf), _ptr(V.buf), Nt, Nv, H, d, PREC[T.precision],
+              float(T.prescale), _ptr(gt_col), int(col0), _ptr(s_gt64), _ptr(band_t), _ptr(band_v), _ptr(count), _ptr(pairs))
     return RankState(Et, Ev, T, V, H, gt_col, int(col0), s_gt64, band_t, band_v, count, pairs, cap)
 
 

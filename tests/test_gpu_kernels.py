@@ -962,3 +962,33 @@ def test_fused_tail_equals_resolve_then_metrics(name, prec, monkeypatch):
         check_metrics_flag(pinned)
         assert tuple(pinned[:7].tolist()) == tuple(got['metrics'])
         assert torch.equal(out['ranks'], ref['ranks'])
+
+
+@pytest.mark.parametrize('prec', ['fp16', 'bf16'])
+@pytest.mark.parametrize('Nt,Nv,H,d', [(1000, 333, 1, 512), (257, 64, 8, 64), (5000, 1250, 1, 512)])
+def test_rank_prepare_emit_equals_pack_then_prepare(Nt, Nv, H, d, prec):
+    """laff_rank_prepare_emit (ops.rank_prepare with T or V None) produces the operand of unit-norm rows itself: bit for bit the buffer
+    pack_rows(E, normalize=False) writes, and the state (exact ground-truth scores, both bands, cleared accumulators) of the plain
+    laff_rank_prepare on that operand -- for the text side, the video side and both."""
+    from laff_amd import ops
+    g = rnd(Nt + Nv + H)
+    te = g.normal(0, 1, (Nt, H, d)).astype(np.float32)
+    ve = g.normal(0, 1, (Nv, H, d)).astype(np.float32)
+    te /= np.linalg.norm(te, axis=2, keepdims=True)
+    ve /= np.linalg.norm(ve, axis=2, keepdims=True)
+    Et, Ev = dev(te), dev(ve)
+    gt = dev(g.integers(0, Nv, Nt).astype(np.int32), torch.int32)
+    T = ops.pack_rows(Et, False, 1e-13, prec)
+    V = ops.pack_rows(Ev, False, 1e-13, prec)
+    ref = ops.rank_prepare(Et, Ev, T, V, gt)
+    for t_in, v_in in ((None, V), (T, None), (None, None)):
+        st = ops.rank_prepare(Et, Ev, t_in, v_in, gt, emit_precision=prec)
+        assert torch.equal(st.T.buf[:Nt * H * d * 2], T.buf[:Nt * H * d * 2]) and torch.equal(st.V.buf[:Nv * H * d * 2], V.buf[:Nv * H * d * 2])
+        assert st.T.precision == prec and st.V.prescale == T.prescale
+        assert torch.equal(st.s_gt64, ref.s_gt64)
+        assert torch.equal(st.band_t[:Nt], ref.band_t[:Nt])
+        nb = ((Nv + 3) & ~3) + (Nv + 63) // 64
+        assert torch.equal(st.band_v[:Nv], ref.band_v[:Nv]) and torch.equal(st.band_v[(Nv + 3) & ~3:nb], ref.band_v[(Nv + 3) & ~3:nb])
+        assert int(st.count.abs().sum()) == 0 and st.pairs[:2].tolist() == [0, 0]
+    with pytest.raises(ValueError):
+        ops.rank_prepare(Et, Ev, None, None, gt, emit_precision='fp16x3')
