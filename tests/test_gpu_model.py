@@ -317,6 +317,38 @@ def test_bench_line_contract():
     assert line['sustained']['seconds'] >= 1.9
     assert {v['kind'] for v in line['cpu_baseline']['variants']} == {'port-blockloop-argsort', 'port-vectorised'}
     assert abs(line['cpu_baseline']['r1'] - line['quality']['R@1']) < 1e-9
+    # round 5: per-kernel figures from stamps inside a capture of the timed step (every launch of the step listed, adding up to the
+    # instrumented span), the strict mode, one rank's share of an 8-rank pass in both decompositions
+    assert 'stamps' in line['kernels_source'] and line['stages_ms_eager_pass'] is None
+    sb = line['step_breakdown']
+    assert sb['launches'] == sum(k['launches_per_step'] for k in line['kernels'].values())
+    assert abs(sb['kernels_ms'] + sb['gaps_ms'] + sb['launches'] * sb['stamp_cost_ms'] - sb['instrumented_span_ms']) <= 0.02 * sb['instrumented_span_ms'] + 1e-3
+    assert {'fc_act_bn', 'fuse', 'sim_gemm', 'rank_resolve'} <= set(line['kernels'])
+    assert line['roofline']['kernel'] is not None and line['roofline']['frac'] is not None
+    assert line['strict_mode']['precision'] == 'fp16x3' and line['strict_mode']['metrics_equal_to_headline_mode'] is True
+    emu = {e['scheme']: e for e in line['shard_emulation']}
+    assert set(emu) == {'text', 'video'} and all(e['metrics_equal_to_unsharded'] and e['ms_per_step'] > 0 for e in emu.values())
+
+
+def test_bench_emulate_shard_line():
+    """bench.py --emulate-shard G: ONE line whose headline is rank 0's share of a G-rank pass (no collectives), ranks and metrics equal to
+    the un-sharded pass (the bench raises otherwise)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for shard in ('text', 'video'):
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'tiny', '--steps', '4', '--warmup', '1',
+                              '--emulate-shard', '3', '--shard', shard], capture_output=True, text=True, timeout=900, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1
+        line = json.loads(lines[0])
+        e = line['shard_emulation'][0]
+        assert e['scheme'] == shard and e['ranks_of'] == 3 and e['metrics_equal_to_unsharded'] is True
+        assert 'EMULATED' in line['config']['workload'] and line['n_gpus'] == 1 and line['value'] > 0
+        assert e['score_block'] == ([171, 192] if shard == 'text' else [512, 64])
 
 
 def test_evaluation_cosine_sim_golden(golden):
