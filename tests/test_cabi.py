@@ -133,3 +133,26 @@ def test_fc_strip_kernels_keep_out_of_the_accumulator_registers(tmp_path):
         meta = text[text.index('.name:           ' + name):]
         assert int(re.search(r'\.vgpr_spill_count: (\d+)', meta).group(1)) == 0
         assert int(re.search(r'\.sgpr_spill_count: (\d+)', meta).group(1)) == 0
+
+
+def _build_c_host(out_dir):
+    """tests/c_host/laff_host.c: plain C11 against include/laff_hip.h, built with gcc (no hipcc, no torch) and linked to the library."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'tests', 'c_host', 'laff_host.c')
+    exe = os.path.join(str(out_dir), 'laff_host')
+    libdir = os.path.join(root, 'laff_amd', 'lib')
+    cmd = ['gcc', '-std=c11', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', '-I' + os.path.join(root, 'include'), src,
+           '-o', exe, '-L' + libdir, '-llaff_hip', '-L/opt/rocm/lib', '-lamdhip64', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_c_host_builds_against_the_header(tmp_path):
+    """The C ABI is bindable from plain C: the host program of tests/c_host compiles with gcc -std=c11 -Werror against the header alone and
+    links to liblaff_hip.so (it runs in the GPU suite: test_gpu_kernels.py::test_c_host_runs_the_exact_rank_tail)."""
+    from laff_amd import build
+    build.build_library(verbose=False)
+    exe = _build_c_host(tmp_path)
+    assert os.path.exists(exe)

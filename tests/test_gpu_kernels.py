@@ -992,3 +992,40 @@ def test_rank_prepare_emit_equals_pack_then_prepare(Nt, Nv, H, d, prec):
         assert int(st.count.abs().sum()) == 0 and st.pairs[:2].tolist() == [0, 0]
     with pytest.raises(ValueError):
         ops.rank_prepare(Et, Ev, None, None, gt, emit_precision='fp16x3')
+
+
+def test_c_host_runs_the_exact_rank_tail(tmp_path):
+    """A host without Python or torch (tests/c_host/laff_host.c: gcc, hipMalloc'ed buffers, the C ABI only) runs prepare (producing both
+    operands) -> banded GEMM -> resolve + metrics: ranks equal to the ranks of float64 scores of the same embeddings, evaluation.eval's
+    numbers equal to the oracle's, scores within the fp16 contract."""
+    import os
+    import subprocess
+    import sys
+    from oracle import laff_oracle as O
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_cabi import _build_c_host
+    exe = _build_c_host(tmp_path)
+    g = rnd(2024)
+    Nt, Nv, H, d = 3000, 700, 2, 128
+    z = g.normal(0, 1, (Nv, H, d)).astype(np.float32)
+    gt = (np.arange(Nt) % Nv).astype(np.int32)
+    te = (z[gt] + 5.0 * g.normal(0, 1, (Nt, H, d))).astype(np.float32)
+    ve = z.copy()
+    te /= np.linalg.norm(te, axis=2, keepdims=True)
+    ve /= np.linalg.norm(ve, axis=2, keepdims=True)
+    prob, out = str(tmp_path / 'problem.bin'), str(tmp_path / 'out.bin')
+    with open(prob, 'wb') as f:
+        np.array([Nt, Nv, H, d], np.int32).tofile(f)
+        te.tofile(f); ve.tofile(f); gt.tofile(f)
+    r = subprocess.run([exe, prob, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-500:]
+    raw = open(out, 'rb').read()
+    ranks = np.frombuffer(raw, np.int32, Nt, 0)
+    metrics = np.frombuffer(raw, np.float64, 7, 4 * Nt)
+    S = np.frombuffer(raw, np.float32, Nt * Nv, 4 * Nt + 56).reshape(Nt, Nv)
+    S64 = O.txt2vis_matrix_f64(te, ve)
+    want = O.count_ranks(S64, gt)
+    assert np.array_equal(ranks, want)
+    assert len(set(ranks.tolist())) > 8
+    np.testing.assert_allclose(metrics, O.eval_from_positions([[x] for x in want.astype(np.float64)]), rtol=1e-12, atol=0)
+    assert float(np.abs(S - S64).max()) <= 1e-4
