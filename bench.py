@@ -605,16 +605,22 @@ def main():
                                 metrics_out=pins[slot] if async_metrics else None, runner=runner, state=state,
                                 force_collectives=force_dist, finish_tag=str(slot))
 
+    power_w = []
+
     def sclk_sampler(stop, out):
-        # shader clock actually held during a loop (the chip clocks to its power budget: MI355X_MICROARCH.md "DVFS give-back")
+        # shader clock actually held during a loop, and the package power beside it (the chip clocks to its power budget:
+        # MI355X_MICROARCH.md "DVFS give-back"; at 1,400 W the pass is bound by its energy, not by any one pipe)
         import re
         import subprocess
         while not stop.is_set():
             try:
-                txt_ = subprocess.run(['rocm-smi', '--showclocks'], capture_output=True, text=True, timeout=5).stdout
+                txt_ = subprocess.run(['rocm-smi', '--showclocks', '--showpower'], capture_output=True, text=True, timeout=5).stdout
                 m = re.findall(r'sclk clock level:? *\d*:? *\((\d+)Mhz\)', txt_)
                 if m:
                     out.append(int(m[local_rank if local_rank < len(m) else 0]))
+                pw = re.findall(r'Package Power \(W\): *([0-9.]+)', txt_)
+                if pw:
+                    power_w.append(float(pw[local_rank if local_rank < len(pw) else 0]))
             except Exception:  # noqa: BLE001
                 return
 
@@ -842,7 +848,11 @@ def main():
             stop.set()
             th.join(timeout=6)
             sustained = {'seconds': round(dt_s, 2), 'steps': n_s, 'ms_per_step': round(1e3 * dt_s / n_s, 4),
-                         'value': float(Nt) * Nv * n_s / dt_s, 'sclk_mhz_samples': clocks[:8]}
+                         'value': float(Nt) * Nv * n_s / dt_s, 'sclk_mhz_samples': clocks[:8],
+                         # (the first sample is taken while the loop starts; the rest sit at the package cap: the pass is energy-bound)
+                         'package_power_w_samples': power_w[:8],
+                         'joules_per_step': (round(1e-3 * dt_s / n_s * (sum(power_w[1:8]) / len(power_w[1:8])) * 1e3, 4)
+                                             if len(power_w) > 1 else None)}
         # (ii) the count-only mode (ranks + metrics, S never written): what the similarity GEMM does when the caller does not ask for
         # the score matrix (with K = 512 the fp32 S store is the HBM-bound part; without it the GEMM is MFMA-bound)
         g2 = []
