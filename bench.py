@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+GRAPH_CHECK_REPLAYS = 64       # replays of the two captured steps that are checked against the eager step before the W warm-up replays
 MFMA_PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0, 'bf16': 2500.0}
 
 
@@ -666,7 +667,7 @@ def main():
             graph, runner = None, None
             torch.cuda.synchronize()
             res = step(False)
-    launch_mode = ('HIP graph replay, step k+1 enqueued while the host reads the metrics of step k; the two captures are checked against the eager step (16 replays) before the W warm-up replays' if graph is not None else
+    launch_mode = ('HIP graph replay, step k+1 enqueued while the host reads the metrics of step k; the two captures are checked against the eager step (%d pipelined replays, every one compared) before the W warm-up replays' % GRAPH_CHECK_REPLAYS if graph is not None else
                    ('per-phase HIP graphs + eager RCCL, step k+1 issued while the host reads the metrics of step k'
                     if runner is not None else 'eager'))
 
@@ -715,17 +716,26 @@ def main():
     # the GPU idles and drops its clocks -- with the warm-up in front of it the first timed steps ran on a chip still ramping up:
     # 1.19 ms per step over 20 steps against 1.115 sustained.)
     if graph is not None:
-        # graph self-check: both captures, replayed alternately, must reproduce the eager step's seven metrics every time.  (16 replays
-        # = ~20 ms of device work; they also bring the chip out of the low clock state the capture leaves it in -- the first ~18 steps
-        # after an idle phase run 5-15 % slow: LAFF_BENCH_STEP_TRACE=1 prints the per-step intervals.)
+        # graph self-check: both captures, replayed alternately the way the timed loop replays them (two in flight, the host reads the
+        # metrics of replay k - 1 while replay k runs), must reproduce the eager step's seven metrics EVERY time.  GRAPH_CHECK_REPLAYS
+        # replays = ~60 ms of device work; they also bring the chip out of the state the capture (host work, idle GPU) leaves it in -- the
+        # package needs tens of milliseconds of load to settle at its power cap, and the first steps behind an idle phase run 3-5 %
+        # slow: LAFF_BENCH_STEP_TRACE=1 prints the per-step intervals.
         want = eager_metrics
-        for k in range(16):
-            graphs[k % 2].replay()
-            torch.cuda.current_stream().synchronize()
+        ev_c = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def check_replay(k):
+            ev_c[k % 2].synchronize()
             check_metrics_flag(pins[k % 2])
             got = tuple(pins[k % 2][:7].tolist())
             if want is not None and got != want:
                 raise RuntimeError('graph replay %d gave metrics %s, the eager step %s' % (k, got, want))
+        for k in range(GRAPH_CHECK_REPLAYS):
+            graphs[k % 2].replay()
+            ev_c[k % 2].record()
+            if k:
+                check_replay(k - 1)
+        check_replay(GRAPH_CHECK_REPLAYS - 1)
     for k in range(args.warmup):
         if graph is not None:
             graphs[k % 2].replay()
