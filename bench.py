@@ -292,22 +292,28 @@ def dryrun_main(args):
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         out[kind] = (float(el.item()), res)
     if rank == 0:
-        el, res = out['video']
+        from laff_amd.dist import choose_sharding
+        head = choose_sharding(Nt, Nv) if args.shard == 'auto' else args.shard
+        others = [k for k in ('video', 'text', 'video16') if k != head]
+        el, res = out[head]
         m = res['metrics']
+
+        def gb(k):
+            return gathered_bytes(k, Nt, Nv, Wt.shape[1], world, 4096) if k == 'video16' else gathered_bytes(k, Nt, Nv, Wt.shape[1], world)
         line = {'metric': 'text-video cosine pairs/sec', 'value': float(Nt) * Nv * args.steps / el, 'unit': 'pairs/s', 'n_gpus': world,
                 'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                 'dtype': 'dry run (numpy oracle stand-in)', 'data': 'synthetic',
                 'config': {'workload': 'DRYRUN %d texts x %d videos (CPU, gloo): exercises the launcher, not the kernels' % (Nt, Nv),
-                           'shard': 'video', 'backend': 'gloo'},
-                'alt_shard': {'shard': 'text', 'ms_per_step': 1e3 * out['text'][0] / args.steps,
-                              'ranks_equal': bool(torch.equal(out['text'][1]['ranks'], res['ranks']))},
+                           'shard': head, 'shard_arg': args.shard, 'backend': 'gloo'},
+                'alt_shard': {'shard': others[0], 'ms_per_step': 1e3 * out[others[0]][0] / args.steps,
+                              'ranks_equal': bool(torch.equal(out[others[0]][1]['ranks'], res['ranks']))},
                 'alt_shards': [{'shard': k, 'ms_per_step': 1e3 * out[k][0] / args.steps,
                                 'ranks_equal': bool(torch.equal(out[k][1]['ranks'], res['ranks'])),
-                                'gathered_bytes_per_step': gathered_bytes(k, Nt, Nv, Wt.shape[1], world, 4096)} for k in ('text', 'video16')],
-                'gathered_bytes_per_step': gathered_bytes('video', Nt, Nv, Wt.shape[1], world),
-                'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3]}, 'collective_ms': None,
-                'roofline': None, 'cpu_baseline': None}
+                                'gathered_bytes_per_step': gb(k)} for k in others],
+                'gathered_bytes_per_step': gb(head),
+                'quality': {'R@1': m[0], 'R@5': m[1], 'R@10': m[2], 'MedR': m[3], 'meanr': m[4], 'mir': m[5], 'mAP': m[6]},
+                'collective_ms': None, 'roofline': None, 'cpu_baseline': None}
         os.write(json_fd, (json.dumps(line) + '\n').encode())
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -481,13 +487,13 @@ def main():
     ap.add_argument('--fc-precision', default='fp16x3', help="FC projections: fp32 (fp32 MFMA) | fp16x3 (exact fp16 hi/lo split)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='time eager launches instead of HIP-graph replays')
-    ap.add_argument('--shard', default='auto', choices=['auto', 'video', 'text', 'video16'],
-                    help="N > 1 decomposition of the headline number: 'auto' (default) = 'text' / 'video', whichever gathers fewer rows "
-                         "(laff_amd.dist.choose_sharding: at 40k x 10k the videos are the smaller side, 2 collective rounds instead of 3); "
-                         "'video' (BASELINE.json's wording: video-row shards, all-gather of the text embeddings, two small all-reduces), "
+    ap.add_argument('--shard', default='video', choices=['auto', 'video', 'text', 'video16'],
+                    help="N > 1 decomposition of the headline number: 'video' (default; BASELINE.json's wording: video-row shards, all-gather "
+                         "of the text embeddings, two small all-reduces), 'auto' = 'text' / 'video', whichever gathers fewer rows "
+                         "(laff_amd.dist.choose_sharding: at 40k x 10k the videos are the smaller side, 2 collective rounds instead of 3), "
                          "'text' (text-row shards, all-gather of the video embeddings, no all-reduce), 'video16' (video-row shards with the "
                          "16-bit text operand + the fp32 video rows gathered and the in-band pairs sent to the owner of their text row).  "
-                         "The other schemes are timed too and reported beside it (alt_shards)")
+                         "The other schemes are timed too and reported beside it (alt_shards); config.shard names the one `value` is for")
     ap.add_argument('--emulate-shard', type=int, default=0, metavar='G',
                     help="one GPU: time rank 0's share of a G-rank pass of this workload with no collectives (laff_amd.dist.EmulatedComm: "
                          "the peers' gathered rows / reduced values are pre-filled) instead of the whole problem; the scheme is --shard")

@@ -424,9 +424,7 @@ int laff_fc_act_bn_fused_grouped(laff_ctx* ctx, const laff_fc_fused_problem* pro
         a.row_scale = q.x_rscale; a.col_scale = q.w_rscale;
         a.bias = q.bias; a.bn_scale = q.bn_scale; a.bn_shift = q.bn_shift; a.act = q.act;
 #ifdef LAFF_GEMM_TRACE
-    #ifdef LAFF_GEMM_TRACE
-    if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
-#endif
+        if (const char* e = getenv("LAFF_GEMM_TRACE_PTR")) a.trace = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
         ga.p[ga.count++] = a;
         if (ga.count == laff::MAX_GROUP) {

@@ -16,12 +16,14 @@ static inline hipError_t smem_attr_once(unsigned long long& done, K kernel, int 
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
-    if (done & bit) return hipSuccess;
+    // (atomic: two host threads driving two contexts must not lose each other's bit -- a lost bit would repeat the call, possibly
+    // inside a capture)
+    if (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
     if (smem > 64 * 1024) {
         e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return e;
     }
-    done |= bit;
+    __atomic_fetch_or(&done, bit, __ATOMIC_ACQ_REL);
     return hipSuccess;
 }
 

@@ -10,6 +10,22 @@
 #include "kernels.h"
 #include "exact_cos.h"
 
+// Cross-workgroup hand-off of the metrics tails (rank_metrics_kernel, rank_resolve_kernel).  Default: no fences -- the partials travel
+// as device-scope stores / atomics, are complete once `s_waitcnt vmcnt(0)` returns, and the ticket is a relaxed device-scope atomic behind
+// that wait: this is gfx9 hardware behaviour (vmcnt covers stores, device-scope atomics are performed memory-side), not a guarantee of
+// the HIP memory model.  -DLAFF_TAIL_FENCES restores the model's own release / acquire pair around the tickets (an L2 write-back +
+// invalidate per workgroup: 12 us slower at C4); tests/test_gpu_kernels.py::test_fence_free_tail_equals_the_fenced_build holds the two
+// builds against each other over many replays.
+#ifdef LAFF_TAIL_FENCES
+#define LAFF_TICKET_ORDER __ATOMIC_ACQ_REL
+#define LAFF_TAIL_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define LAFF_TAIL_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define LAFF_TICKET_ORDER __ATOMIC_RELAXED
+#define LAFF_TAIL_RELEASE() do {} while (0)
+#define LAFF_TAIL_ACQUIRE() do {} while (0)
+#endif
+
 namespace laff {
 
 __global__ void gather_gt_kernel(const float* __restrict__ S, int Nt, int Nv, long lds, const int* __restrict__ gt_col,
@@ -380,7 +396,8 @@ struct MetricsLds {
 constexpr size_t RESOLVE_POOL_BYTES = sizeof(MetricsLds) > 4 * RESOLVE_QCAP * 8 ? sizeof(MetricsLds) : 4 * RESOLVE_QCAP * 8;
 
 template <int NT>
-__device__ void metrics_single_block(const int* r, int n, int base, int* ranks_out, double* out8, double* host8, MetricsLds& L) {
+__device__ void metrics_single_block(const int* r, int n, int base, int* ranks_out, double* out8, double* host8, MetricsLds& L,
+                                     bool force_bad = false) {
     static_assert(NT == 256, "select_bin below wants exactly four wavefronts");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // One CU does all of this with one wavefront per SIMD, so the per-rank work is kept to a handful of integer instructions (the
@@ -517,7 +534,7 @@ __device__ void metrics_single_block(const int* r, int n, int base, int* ranks_o
     __syncthreads();
     if (tid == 0) { L.hist[1] = n1; L.hist[256] = (unsigned)n - nbig - nmid; }      // lo[1] and hi[0] = #{v < 256} were counted in registers
     __syncthreads();
-    if (n > 0 && mn < 1) {                                        // invalid input: flag + NaN metrics
+    if ((n > 0 && mn < 1) || force_bad) {                         // invalid input (or a list that overflowed): flag + NaN metrics
         if (tid < 7) { out8[tid] = __builtin_nan(""); if (host8) host8[tid] = __builtin_nan(""); }
         if (tid == 7) { out8[7] = 1.0; if (host8) host8[7] = 1.0; }
         return;
@@ -606,6 +623,24 @@ __device__ void metrics_single_block(const int* r, int n, int base, int* ranks_o
     }
 }
 
+// A list that overflowed: flag in the header + count[0] pushed below every legitimate value, both as DEVICE-SCOPE atomics -- a plain
+// store may sit dirty in this XCD's L2 where neither the fused metrics tail's finishing workgroup (another XCD, no release fence on
+// this side) nor the next launch's atomics on count[0] would meet it.  (The add survives concurrent +1 updates of count[0].)
+__device__ __forceinline__ void poison_overflow(unsigned* pairs, int* count) {
+    __hip_atomic_store(pairs + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(count, -(1 << 26), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the overflow condition of either list format, from the header the GEMM launch left (complete before this launch started)
+__device__ __forceinline__ bool list_overflowed(const unsigned* pairs, unsigned pair_cap) {
+    if (pairs[2] & 0x80000000u) {
+        const unsigned taken = pairs[0], NW = pairs[2] & 0x7fffffffu, NCH = pairs[3];
+        return pairs[1] != 0u || NW > NCH || taken > NCH - (NW < NCH ? NW : NCH);
+    }
+    const unsigned n_over = pairs[0], regA = pairs[2];
+    const unsigned long long room = pair_cap > regA ? pair_cap - regA : 0u;
+    return pairs[1] != 0u || n_over > room;
+}
+
 // ---- the strip kernel's list (sim_strip.hip): header {chunks taken from the pool, overflow flag, NW | 1 << 31, NCH} | NCH per-chunk
 // entry counts (rounded up to 4 words) | NCH chunks of STRIP_CHUNK entries of STRIP_ENTRY_WORDS words.  Chunks 0 .. NW - 1 belong to
 // the GEMM's wavefronts, chunks NW .. NW + taken - 1 were taken from the pool; the first count[c] entries of chunk c are valid.
@@ -623,7 +658,7 @@ __device__ __forceinline__ void resolve_groups(const float* __restrict__ Et, con
     const unsigned taken = pairs[0], NW = pairs[2] & 0x7fffffffu, NCH = pairs[3];
     const unsigned cnt_words = (NCH + 3u) & ~3u;
     if (pairs[1] != 0u || NW > NCH || taken > NCH - (NW < NCH ? NW : NCH)) {            // the pool ran out: entries were dropped
-        if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[1] = 1u; count[0] = -(1 << 26); }
+        if (blockIdx.x == 0 && threadIdx.x == 0) poison_overflow(pairs, count);
     }
     const unsigned long long nchunks = (unsigned long long)NW + taken < NCH ? (unsigned long long)NW + taken : NCH;
     const unsigned long long slots = nchunks * STRIP_CHUNK;
@@ -716,6 +751,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
     float* __restrict__ S, long lds, unsigned* __restrict__ pairs, unsigned pair_cap, MetricsTail mt) {
     __shared__ __attribute__((aligned(16))) unsigned char pool[RESOLVE_POOL_BYTES];      // the pair queues, then the metrics tail's state
     unsigned (*queue)[RESOLVE_QCAP][2] = reinterpret_cast<unsigned (*)[RESOLVE_QCAP][2]>(pool);
+    // read before block 0 raises pairs[1]: every workgroup derives the same answer from what the GEMM launch left in the header, so the
+    // finishing workgroup of the metrics tail does not depend on seeing block 0's poison
+    const bool overflowed = list_overflowed(pairs, pair_cap);
     if (pairs[2] & 0x80000000u)             // the strip kernel's list (sim_strip.hip): dumped groups of 16 raw accumulators
         resolve_groups(Et, Ev, H, d, s_gt64, count, S, lds, pairs, pair_cap, queue);
     else
@@ -737,9 +775,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
         const unsigned ngroups = gridDim.x < RESOLVE_TICKET_GROUPS ? gridDim.x : RESOLVE_TICKET_GROUPS;
         unsigned* const tg = mt.ticket + 64u * (1u + g);
         unsigned last = 0u;
-        if (__hip_atomic_fetch_add(tg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsz - 1u) {
+        LAFF_TAIL_RELEASE();
+        if (__hip_atomic_fetch_add(tg, 1u, LAFF_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == gsz - 1u) {
             __hip_atomic_store(tg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(mt.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u) {
+            if (__hip_atomic_fetch_add(mt.ticket, 1u, LAFF_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u) {
                 __hip_atomic_store(mt.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 last = 1u;
             }
@@ -749,7 +788,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void r
     __syncthreads();
     if (!s_ticket) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");            // one L2 invalidate in one workgroup (no write-back)
-    metrics_single_block<256>(count, mt.n, mt.base, mt.ranks_out, mt.out8, mt.host8, *reinterpret_cast<MetricsLds*>(pool));
+    metrics_single_block<256>(count, mt.n, mt.base, mt.ranks_out, mt.out8, mt.host8, *reinterpret_cast<MetricsLds*>(pool), overflowed);
 }
 
 // the tiled kernel's list: header {n_overflow, overflow flag, A, chunk}, A slots in per-wavefront segments, then the overflow pairs
@@ -765,7 +804,7 @@ __device__ __forceinline__ void resolve_pairs(const float* __restrict__ Et, cons
     if (n_over > room) {
         // the poison survives an int32 all-reduce(SUM) over up to 16 shards (laff_amd/dist.py 'video' scheme): 16 * -(2^26) = -2^30 does
         // not wrap, and no legitimate count (< 2^26 videos) lifts it back above zero
-        if (blockIdx.x == 0 && threadIdx.x == 0) { pairs[1] = 1u; count[0] = -(1 << 26); }
+        if (blockIdx.x == 0 && threadIdx.x == 0) poison_overflow(pairs, count);
     }
     auto one = [&](unsigned r, unsigned c, bool ok) {
         const double ex = exact_cos(Et + (long)r * K, Ev + (long)c * K, H, d, sl);
@@ -854,7 +893,7 @@ __global__ __launch_bounds__(256) void rank_export_kernel(const double* __restri
         return (unsigned)o;
     };
     unsigned qn = 0;                                                         // wave-uniform
-    auto poison = [&]() { x.fill[x.world] = 1u; pairs[1] = 1u; count[0] = -(1 << 26); };
+    auto poison = [&]() { __hip_atomic_store(x.fill + x.world, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); poison_overflow(pairs, count); };
     auto drain = [&]() {
         for (int o = 0; o < x.world; ++o) {
             unsigned n_o = 0;
@@ -1076,9 +1115,13 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_ticket = __hip_atomic_fetch_add(scratch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        LAFF_TAIL_RELEASE();
+        s_ticket = __hip_atomic_fetch_add(scratch, 1u, LAFF_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     if (s_ticket != (unsigned)(G - 1)) return;
+    LAFF_TAIL_ACQUIRE();
 
     // ---- the last block
     {

@@ -50,13 +50,24 @@ class TorchComm:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.active = self.world > 1 or (force and dist.is_initialized())
 
+    @staticmethod
+    def _not_capturing(what, t):
+        """The collectives of a pass are EAGER calls between the per-phase HIP graphs (GraphRunner): RCCL under stream capture is not
+        proven on this stack, and a collective recorded into a capture by accident would be replayed without its peers.  Fail loudly."""
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('laff_amd.dist: %s issued while a HIP-graph capture is open on this stream; the collectives of a sharded '
+                               'pass run eagerly between the captured phases (GraphRunner.phase)' % what)
+
     def all_gather(self, out, send, async_op=False):
+        self._not_capturing('all_gather', send)
         return dist.all_gather_into_tensor(out, send, group=self.group, async_op=async_op)
 
     def all_reduce(self, t, op):
+        self._not_capturing('all_reduce', t)
         dist.all_reduce(t, op={'max': dist.ReduceOp.MAX, 'sum': dist.ReduceOp.SUM}[op], group=self.group)
 
     def all_to_all(self, out, send):
+        self._not_capturing('all_to_all', send)
         dist.all_to_all_single(out, send, group=self.group)
 
 

@@ -200,3 +200,23 @@ def test_emulated_rank_of_a_sharded_pass(world, rank):
     res = evaluate_sharded_by_text(be, vis_l, txt_l, gt_t, Nt, Nv, 1, state=state, comm_impl=EmulatedComm(world, rank))
     assert np.array_equal(res['ranks'].numpy(), single['ranks'].numpy())
     np.testing.assert_allclose(res['S_local'].numpy(), single['S_local'].numpy()[t0:t1], rtol=0, atol=1e-6)
+
+
+def test_collectives_refuse_an_open_capture(monkeypatch):
+    """TorchComm's collectives are eager calls between the captured phases; issued while a HIP-graph capture is open they raise instead
+    of being recorded (replayed without their peers).  The capture state is stubbed: there is no GPU in the CPU suite."""
+    from laff_amd.dist import TorchComm
+
+    class FakeCuda:
+        is_cuda = True
+
+        def __init__(self, n):
+            self.shape = (n,)
+    monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: True)
+    c = TorchComm()
+    for call in (lambda: c.all_gather(FakeCuda(8), FakeCuda(4)), lambda: c.all_reduce(FakeCuda(4), 'sum'),
+                 lambda: c.all_to_all(FakeCuda(4), FakeCuda(4))):
+        with pytest.raises(RuntimeError, match='capture is open'):
+            call()
+    # CPU tensors (the gloo tests) are never inside a capture
+    TorchComm._not_capturing('all_reduce', torch.zeros(2))

@@ -853,6 +853,88 @@ def test_exact_ranks_shard_semantics_and_overflow_flag():
         ops.rank_metrics(st.count, base=1)
 
 
+@pytest.mark.parametrize('strip', [False, True])
+def test_overflow_is_flagged_through_the_fused_tail(strip):
+    """An overflowing pair list driven through laff_rank_resolve_metrics (the one-launch tail): block 0's poison must not be needed by
+    the finishing workgroup (it may sit in another XCD's L2) -- the tail derives the overflow from the list header itself.  Both list
+    formats (the tiled kernel's pairs, the strip kernel's dumps), eager (RuntimeError) and replayed from a captured graph (flag)."""
+    from laff_amd import ops
+    g = rnd(78)
+    if strip:
+        Nt, Nv, H, d = 12288, 4096, 1, 512          # 48 strips x 128 column blocks = 24 units per CU: the strip kernel's threshold
+    else:
+        Nt, Nv, H, d = 900, 400, 1, 128
+    t = g.normal(0, 1, (Nt, H, d)).astype(np.float32)
+    v = (g.normal(0, 1, (Nv, H, d)) * 0.02 + g.normal(0, 1, (1, H, d))).astype(np.float32)      # near-identical videos: many ties
+    gt = dev(g.integers(0, Nv, Nt).astype(np.int32), torch.int32)
+    Et, Ev = dev(t), dev(v)
+    T = ops.pack_rows(Et, True, 1e-13, 'fp16')
+    V = ops.pack_rows(Ev, True, 1e-13, 'fp16')
+    ops.ctx_prepare_metrics(torch.device(DEV))
+    st = ops.rank_prepare(Et, Ev, T, V, gt, pair_cap=8)
+    ops.sim_gemm_banded(st, want_scores=False)
+    with pytest.raises(RuntimeError):
+        ops.rank_resolve_metrics(st)
+    assert st.listed_pairs()[1]
+    pinned = torch.zeros(8, dtype=torch.float64).pin_memory()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, capture_error_mode='thread_local'):
+        st2 = ops.rank_prepare(Et, Ev, T, V, gt, pair_cap=8)
+        ops.sim_gemm_banded(st2, want_scores=False)
+        ops.rank_resolve_metrics(st2, None, pinned)
+    for _ in range(5):
+        pinned.fill_(-1.0)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert pinned[7].item() == 1.0 and np.isnan(pinned[0].item())
+
+
+@pytest.mark.parametrize('mode', ['fused', 'split'])
+def test_fence_free_tail_equals_the_fenced_build(mode, tmp_path):
+    """The metrics tails hand partial results between workgroups without release / acquire fences (gfx9 hardware behaviour, see
+    LAFF_TAIL_FENCES in rank.hip).  The memory model's own form stays one compile switch away: this test builds rank.hip with
+    -DLAFF_TAIL_FENCES, and holds 150 graph replays of {prepare, banded GEMM, tail} on a large grid (1,536 resolve workgroups; 40 metrics
+    workgroups for 'split') of the shipped library against the fenced build: ONE metrics tuple in each, equal to each other."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc on this box')
+    libdir = os.path.join(root, 'laff_amd', 'lib')
+    vdir = str(tmp_path)
+    objs = []
+    for o in os.listdir(libdir):
+        if o.endswith('.o') and o != 'rank.o':
+            objs.append(os.path.join(libdir, o))
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-fPIC', '-fno-gpu-rdc']
+    r = subprocess.run([hipcc] + flags + ['-DLAFF_TAIL_FENCES', '-c', os.path.join(root, 'laff_amd', 'csrc', 'rank.hip'), '-o',
+                                          os.path.join(vdir, 'rank.o')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    vlib = os.path.join(vdir, 'liblaff_hip.so')
+    r = subprocess.run([hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', vlib, os.path.join(vdir, 'rank.o')] + objs,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    script = os.path.join(root, 'tools', 'debug', 'stress_tail.py')
+    outs = []
+    for lib in (None, vlib):
+        env = dict(os.environ)
+        env.pop('LAFF_HIP_LIB', None)
+        if lib:
+            env['LAFF_HIP_LIB'] = lib
+        r = subprocess.run([sys.executable, script, '150', mode], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    for o in outs:
+        assert len(o['distinct']) == 1 and o['distinct'][0][1] == 150, o
+        assert o['distinct'][0][0][7] == '0.0'
+    assert outs[0]['distinct'][0][0] == outs[1]['distinct'][0][0] and outs[0]['rank_sum'] == outs[1]['rank_sum']
+    assert outs[1]['lib'] == vlib
+
+
 def test_c_abi_collectives_on_a_one_rank_group():
     """laff_comm_* / laff_allgather_rows / laff_allreduce_* (include/laff_hip.h, section e) on a 1-rank RCCL communicator: RCCL is found at
     run time, the calls run on torch's stream, and with one rank every collective is the identity."""
