@@ -89,10 +89,13 @@ const char* laff_last_error(void) { return g_err.c_str(); }
 
 int laff_ctx_create(int device, void* hip_stream, laff_ctx** out) {
     if (!out) return fail(LAFF_E_ARG, "laff_ctx_create: null out");
-    if (const char* e = getenv("LAFF_GEMM_VARIANT")) laff::g_gemm_variant = atoi(e);
-    if (const char* e = getenv("LAFF_STRIP")) laff::g_strip_mode = atoi(e);
-    if (const char* e = getenv("LAFF_STRIP_MAP")) laff::g_strip_map = atoi(e);
-    if (const char* e = getenv("LAFF_FC_STRIP")) laff::g_fc_strip = atoi(e);
+    // tuning knobs: process-wide, re-read whenever a ctx is created; an absent variable means the default (not "the last value": a
+    // test that set LAFF_STRIP=2, dropped it and made a new ctx used to leave every later bf16 similarity on the strip kernel)
+    auto knob = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    laff::g_gemm_variant = knob("LAFF_GEMM_VARIANT", 0);
+    laff::g_strip_mode = knob("LAFF_STRIP", 1);
+    laff::g_strip_map = knob("LAFF_STRIP_MAP", 1);
+    laff::g_fc_strip = knob("LAFF_FC_STRIP", 1);
     int n = 0;
     HIP_TRY(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(LAFF_E_ARG, "laff_ctx_create: device %d out of range (%d devices)", device, n);

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from laff_amd import ops
-dev = 'cuda'; N = 8192; K = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = 'cuda'; N = int(sys.argv[3]) if len(sys.argv) > 3 else 8192; K = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 t = torch.nn.functional.normalize(torch.randn(N, K, device=dev), dim=1); v = torch.nn.functional.normalize(torch.randn(N, K, device=dev), dim=1)
 T = ops.pack_rows(t, True, 1e-13, 'fp16'); V = ops.pack_rows(v, True, 1e-13, 'fp16')
 S = torch.empty(N, N, device=dev)
