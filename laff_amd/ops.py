@@ -27,6 +27,10 @@ def _call(name, fn, *args):
     else:
         profiler.begin(name)
         check(fn(*args))
+        rep = getattr(profiler, 'repeat', None)       # tools/energy_table.py: the launch issued n times in a row
+        if rep is not None:
+            for _ in range(rep(name) - 1):
+                check(fn(*args))
         profiler.end(name)
 
 
