@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <bool NT>
@@ -30,7 +31,29 @@ __global__ __launch_bounds__(256, 1) void k(float* S, long ldo, int tiles_c, int
     if (lane == 0) { cyc[(blockIdx.x * 4 + wave) * 2] = t1 - t0; cyc[(blockIdx.x * 4 + wave) * 2 + 1] = t2 - t0; }
 }
 
-int main() {
+// `stprobe2 energy [seconds]`: the G = 256 nt case in a loop, for a joules-per-byte figure (read rocm-smi --showenergycounter around it)
+static int energy_loop(double seconds) {
+    const long N = 16384;
+    float* S; unsigned long long* d_cyc;
+    if (hipMalloc(&S, (size_t)N * N * 4) != hipSuccess || hipMalloc(&d_cyc, 256 * 8 * 8) != hipSuccess) return 1;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int ntiles = 16;
+    (void)hipEventRecord(e0);
+    long launches = 0;
+    float ms = 0;
+    while (ms < seconds * 1e3) {
+        for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k<true>, dim3(256), dim3(256), 0, 0, S, N, (int)(N / 256), ntiles, d_cyc);
+        launches += 200;
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double bytes = (double)launches * 256 * ntiles * 256 * 256 * 4;
+    printf("energy loop: %ld launches, %.1f ms, %.3f GB written, %.2f TB/s\n", launches, ms, bytes * 1e-9, bytes / ms * 1e-9);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'e') return energy_loop(argc > 2 ? atof(argv[2]) : 3.0);
     const long N = 16384;
     float* S; unsigned long long* d_cyc;
     hipMalloc(&S, (size_t)N * N * 4); hipMalloc(&d_cyc, 256 * 8 * 8);
