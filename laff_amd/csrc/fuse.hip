@@ -299,8 +299,17 @@ __device__ __forceinline__ void rank_side_idle(const FuseArgs& a) {
 }
 
 // ---- register-resident variant: d <= 256*NCH ----------------------------------------------------------------
+// Six wavefronts per SIMD (at most 80 VGPRs; <4, 2> took 84 = five): the launch is a chain of load -> ~700 VALU -> store per wavefront that
+// waits 72 % of its cycles (SQ_WAIT_ANY), so resident wavefronts are what keeps loads in flight.  C4 fuse launches 0.153 -> 0.142 ms,
+// C5 2.15 -> 2.01 (A/B on one box, profiles/r6_fuse_occupancy.txt); eight per SIMD (64 VGPRs) spills and loses (0.181).  The step gains
+// only a third of that: the pass is bound by its energy and the shorter launch draws what it saved.
+// (More than eight resident float4 planes per lane -- L * NCH > 8 --, and L = 8, do not fit 80 registers: those instantiations stay unconstrained.)
+#ifndef LAFF_FUSE_WAVES
+#define LAFF_FUSE_WAVES 6
+#endif
+#define LAFF_FUSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((L * NCH <= 8 && L < 8) ? LAFF_FUSE_WAVES : 1)))
 template <int L, int NCH>
-__global__ __launch_bounds__(256) void fuse_reg_kernel(FuseArgs a) {
+__global__ __launch_bounds__(256) LAFF_FUSE_WAVES_ATTR void fuse_reg_kernel(FuseArgs a) {
     const int lane = threadIdx.x & 63;
     long n;
     int h;
