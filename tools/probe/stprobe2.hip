@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 1) void k(float* S, long ldo, int tiles_c, int
 }
 
 // `stprobe2 energy [seconds]`: the G = 256 nt case in a loop, for a joules-per-byte figure (read rocm-smi --showenergycounter around it)
-static int energy_loop(double seconds) {
+static int energy_loop(double seconds, int G, int nt) {
     const long N = 16384;
     float* S; unsigned long long* d_cyc;
     if (hipMalloc(&S, (size_t)N * N * 4) != hipSuccess || hipMalloc(&d_cyc, 256 * 8 * 8) != hipSuccess) return 1;
@@ -42,18 +42,21 @@ static int energy_loop(double seconds) {
     long launches = 0;
     float ms = 0;
     while (ms < seconds * 1e3) {
-        for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k<true>, dim3(256), dim3(256), 0, 0, S, N, (int)(N / 256), ntiles, d_cyc);
+        for (int i = 0; i < 200; ++i) {
+            if (nt) hipLaunchKernelGGL(k<true>, dim3(G), dim3(256), 0, 0, S, N, (int)(N / 256), ntiles, d_cyc);
+            else hipLaunchKernelGGL(k<false>, dim3(G), dim3(256), 0, 0, S, N, (int)(N / 256), ntiles, d_cyc);
+        }
         launches += 200;
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         (void)hipEventElapsedTime(&ms, e0, e1);
     }
-    const double bytes = (double)launches * 256 * ntiles * 256 * 256 * 4;
-    printf("energy loop: %ld launches, %.1f ms, %.3f GB written, %.2f TB/s\n", launches, ms, bytes * 1e-9, bytes / ms * 1e-9);
+    const double bytes = (double)launches * G * ntiles * 256 * 256 * 4;
+    printf("energy loop G %d nt %d: %ld launches, %.1f ms, %.3f GB written, %.2f TB/s\n", G, nt, launches, ms, bytes * 1e-9, bytes / ms * 1e-9);
     return 0;
 }
 
 int main(int argc, char** argv) {
-    if (argc > 1 && argv[1][0] == 'e') return energy_loop(argc > 2 ? atof(argv[2]) : 3.0);
+    if (argc > 1 && argv[1][0] == 'e') return energy_loop(argc > 2 ? atof(argv[2]) : 3.0, argc > 3 ? atoi(argv[3]) : 256, argc > 4 ? atoi(argv[4]) : 1);
     const long N = 16384;
     float* S; unsigned long long* d_cyc;
     hipMalloc(&S, (size_t)N * N * 4); hipMalloc(&d_cyc, 256 * 8 * 8);
