@@ -28,9 +28,24 @@ def timed(fn, secs, label):
     ms=e0.elapsed_time(e1)/n
     print(label,'ms %.4f TF %.1f'%(ms,2.0*Nt*Nv*K/ms/1e9))
     for o in out[:6]: print('   ',o)
+# like for like: both libraries with fp32 output (1.07 GB written) and without it (hipBLASLt: fp16 output, 0.54 GB; laff: count-only --
+# the banded rank count in the epilogue, no score matrix)
 timed(lambda: ops.sim_gemm(T,V,out=S), 3.0, 'laff sim_gemm fp16 16384x16384x4096 (fp32 out)')
+try:
+    C32=torch.empty(Nt,Nv,device=dev,dtype=torch.float32)
+    timed(lambda: torch.mm(a16,b16.t(),out_dtype=torch.float32,out=C32), 3.0, 'torch.mm fp16 (hipBLASLt) fp32 out (out_dtype)')
+    del C32
+except Exception as e:
+    print('torch.mm out_dtype=float32 not available:', repr(e)[:200])
 C=torch.empty(Nt,Nv,device=dev,dtype=torch.float16)
 timed(lambda: torch.matmul(a16,b16.t(),out=C), 3.0, 'torch.matmul fp16 (hipBLASLt) fp16 out')
+gt=(torch.arange(Nt,device=dev)%Nv).int()
+st=ops.rank_prepare(t.reshape(Nt,1,K),v.reshape(Nv,1,K),T,V,gt)
+def count_only():
+    st.pairs[:4].zero_(); st.count.zero_()
+    ops.sim_gemm_banded(st, want_scores=False)
+timed(count_only, 3.0, 'laff sim_gemm_banded fp16 16384x16384x4096 count-only (no output matrix; + two one-block clears per launch)')
+del st
 a=torch.randn(40000,512,device=dev).half(); b=torch.randn(10000,512,device=dev).half()
 Nt,Nv,K=40000,10000,512
 C2=torch.empty(40000,10000,device=dev,dtype=torch.float16)
