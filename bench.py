@@ -1027,7 +1027,9 @@ def main():
             pk['flops_counted'] = 'executed: 3 fp16 MFMA products per algorithmic MAC (fp32-class accuracy on the fp16 pipe)'
             pk['achieved_algorithmic'] = round(alg, 2)
             pk['frac_algorithmic'] = round(alg / MFMA_PEAK_TFLOPS['f16'], 4)
-            pk['frac_algorithmic_vs_f32_mfma_peak'] = round(alg / MFMA_PEAK_TFLOPS['f32'], 4)
+            # (not a fraction of a roof: how many times the fp32 matrix pipe's PEAK the algorithmic rate is -- why the FC runs as three
+            # fp16 products instead of on v_mfma_f32_32x32x2_f32)
+            pk['algorithmic_rate_over_f32_mfma_peak'] = round(alg / MFMA_PEAK_TFLOPS['f32'], 3)
         if 'fuse' in per_kernel:
             # `achieved` = SURVEY section 8d's bytes (planes in, embeddings out).  The launches also write the 16-bit GEMM operand and,
             # with laff_fuse_packed_rank, read every text's ground-truth video row (L2 / Infinity Cache): what they actually move
