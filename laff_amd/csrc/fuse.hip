@@ -67,6 +67,55 @@ __device__ __forceinline__ float4 load_plane(const FuseArgs& a, int l, long n, i
     return v;
 }
 
+// load_plane in two steps, for callers that hold several planes in registers: FIRST every raw load (nothing between them but scalar
+// tests: all of them are in flight together), THEN activation / folded affine / row norm.  As one call per (plane, chunk) hipcc had to
+// finish each value -- the activation switch and the `scale` test are control flow on the loaded data's path -- before it could issue the
+// next load: eight dependent HBM round trips per wavefront in fuse_reg_kernel<4, 2> (found in the ISA: `global_load ... nt ; s_waitcnt
+// vmcnt(0)` eight times over), the 72 % of its cycles that wavefront spent waiting.  Bit for bit the same values as load_plane.
+__device__ __forceinline__ float4 load_plane_raw(const FuseArgs& a, int l, long n, int h, int col) {
+    const int srccol = a.tile[l] ? col : h * a.head_stride + col;
+    typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+    const nt_f32x4 nv = __builtin_nontemporal_load((const nt_f32x4*)(a.src[l] + n * a.ld[l] + srccol));
+    return make_float4(nv.x, nv.y, nv.z, nv.w);
+}
+template <int NCH>
+__device__ __forceinline__ void finish_plane(const FuseArgs& a, int l, long n, int h, int lane, int d, float4 (&x)[NCH]) {
+    const int act = a.act[l];                                   // wave-uniform
+    if (act != LAFF_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float4 v = x[j];
+            if (act == LAFF_ACT_TANH) v = make_float4(plane_tanh(v.x), plane_tanh(v.y), plane_tanh(v.z), plane_tanh(v.w));
+            else if (act == LAFF_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            else if (act == LAFF_ACT_SIGMOID) v = make_float4(plane_sigmoid(v.x), plane_sigmoid(v.y), plane_sigmoid(v.z), plane_sigmoid(v.w));
+            x[j] = v;
+        }
+    }
+    if (a.scale[l]) {
+        float4 sc[NCH], sh[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int col = j * 256 + lane * 4;
+            const int ai = col < d ? (a.tile[l] ? h * a.d + col : h * a.head_stride + col) : 0;    // (columns beyond d: any valid address)
+            sc[j] = *(const float4*)(a.scale[l] + ai);
+            sh[j] = *(const float4*)(a.shift[l] + ai);
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            x[j] = make_float4(fmaf(x[j].x, sc[j].x, sh[j].x), fmaf(x[j].y, sc[j].y, sh[j].y), fmaf(x[j].z, sc[j].z, sh[j].z),
+                               fmaf(x[j].w, sc[j].w, sh[j].w));
+    }
+    if (a.rownorm[l]) {                                          // wave-uniform; l2norm(local_embs, dim=2) of the expert branch
+        const float rn = a.rownorm[l][n];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) x[j] = scl4(x[j], rn);
+    }
+    // columns beyond d hold zeros, whatever the activation made of them
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+        if (j * 256 + lane * 4 >= d) x[j] = make_float4(0, 0, 0, 0);
+}
+
 // out[l][n] = 1 / (|x_l[n, :]|_2 + 1e-13 + 1e-14) over ALL columns of the stacked plane (every head): the factor that
 // `local_embs = l2norm(local_embs, dim=2)` applies after the expert embedding was added (model/model.py:1866-1873, :1686-1694;
 // loss.l2norm, loss.py:8-13).  One wavefront per (row, plane).
@@ -114,6 +163,33 @@ __device__ __forceinline__ void load_gather_plane(const FuseArgs& a, int l, long
             wi = a.g_indices[l][p0 + lane];
             vi = a.g_values[l] ? a.g_values[l][p0 + lane] : 1.0f;
             if (wi < 0 || wi >= dk) { wi = 0; vi = 0.0f; }
+        }
+        if (d == 256 * NCH) {
+            // Whole heads (d = 256 NCH: every lane has all its columns): the rows of GW words are requested together and only then
+            // added, in word order.  (As the generic loop below hipcc emitted ONE load at a time with `s_waitcnt vmcnt(0)` behind it --
+            // the `col < d` test makes every load its own EXEC-masked block with the same destination registers --: 28 dependent
+            // round trips per item at 14 words, the 0.03 ms per row per caption of the C1 launch.)
+#ifndef LAFF_GATHER_GW
+#define LAFF_GATHER_GW 4
+#endif
+            constexpr int GW = LAFF_GATHER_GW;
+            for (int q = 0; q < cnt; q += GW) {                  // lanes >= cnt hold (row 0, weight 0)
+                float4 r[GW][NCH];
+                float v[GW];
+#pragma unroll
+                for (int u = 0; u < GW; ++u) {
+                    const int w = __builtin_amdgcn_readlane(wi, q + u);
+                    v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vi), q + u));
+                    const float* row = wt + (long)w * ldwt + cbase + lane * 4;
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) r[u][j] = *(const float4*)(row + j * 256);
+                }
+#pragma unroll
+                for (int u = 0; u < GW; ++u)
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) acc[j] = fma4(r[u][j], v[u], acc[j]);
+            }
+            continue;
         }
         for (int q = 0; q < cnt; q += 4) {                       // lanes >= cnt hold (row 0, weight 0)
 #pragma unroll
@@ -307,7 +383,10 @@ __device__ __forceinline__ void rank_side_idle(const FuseArgs& a) {
 #ifndef LAFF_FUSE_WAVES
 #define LAFF_FUSE_WAVES 6
 #endif
-#define LAFF_FUSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((L * NCH <= 8 && L < 8) ? LAFF_FUSE_WAVES : 1)))
+#ifndef LAFF_FUSE_WAVES8
+#define LAFF_FUSE_WAVES8 5          // eight resident float4 planes per lane with all their loads in flight: 88 registers
+#endif
+#define LAFF_FUSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(L * NCH <= 6 ? LAFF_FUSE_WAVES : (L * NCH <= 8 && L < 8) ? LAFF_FUSE_WAVES8 : 1)))
 template <int L, int NCH>
 __global__ __launch_bounds__(256) LAFF_FUSE_WAVES_ATTR void fuse_reg_kernel(FuseArgs a) {
     const int lane = threadIdx.x & 63;
@@ -333,18 +412,24 @@ __global__ __launch_bounds__(256) LAFF_FUSE_WAVES_ATTR void fuse_reg_kernel(Fuse
 
     float4 x[L][NCH];
     float4 wv[NCH];
+    // every dense plane's raw values first: L * NCH loads in flight together (see load_plane_raw)
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int col = j * 256 + lane * 4;
+            x[l][j] = (!a.g_wt[l] && col < d) ? load_plane_raw(a, l, n, h, col) : make_float4(0, 0, 0, 0);
+        }
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int col = j * 256 + lane * 4;
-        const bool ok = col < d;
-        wv[j] = (ok && a.w) ? *(const float4*)(a.w + (long)h * d + col) : make_float4(0, 0, 0, 0);
-#pragma unroll
-        for (int l = 0; l < L; ++l)
-            if (!a.g_wt[l]) x[l][j] = ok ? load_plane(a, l, n, h, col) : make_float4(0, 0, 0, 0);
+        wv[j] = (col < d && a.w) ? *(const float4*)(a.w + (long)h * d + col) : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int l = 0; l < L; ++l)
+    for (int l = 0; l < L; ++l) {
         if (a.g_wt[l]) load_gather_plane<NCH>(a, l, n, h, lane, d, x[l]);      // wave-uniform branch
+        else finish_plane<NCH>(a, l, n, h, lane, d, x[l]);
+    }
     if (a.flags & LAFF_ATT_L2NORM_EACH_HEAD) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
