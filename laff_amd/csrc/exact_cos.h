@@ -31,24 +31,43 @@ __device__ __forceinline__ double exact_cos_with(LoadT&& load_t, const float* __
     for (int h = 0; h < H; ++h) {
         const float* vh = v + (long)h * d;
         double tt = 0.0, vv = 0.0, tv = 0.0;
-        // (unrolled: all 16 row loads of a d = 512 head in flight at once -- the resolve kernels are bound by the latency of these
-        // scattered 2 KB rows, and as a rolled loop a pair was eight dependent round trips; the order of the fma chain is unchanged)
-#pragma unroll 8
-        for (int c = sl * 4; c < d; c += RG * 4) {
-            const float4 a = load_t(h, c), b = *(const float4*)(vh + c);
+        auto chain = [&](const float4& a, const float4& b) {
 #ifdef LAFF_EXACT_NOFMA
             tt += (double)(a.x + a.y + a.z + a.w); vv += (double)(b.x + b.y + b.z + b.w); tv += 1.0;
-            continue;
+            return;
 #endif
 #ifdef LAFF_EXACT_TVONLY                  /* timing only: what stored row norms would leave of the chains */
             { const double ax_ = a.x, ay_ = a.y, az_ = a.z, aw_ = a.w, bx_ = b.x, by_ = b.y, bz_ = b.z, bw_ = b.w;
               tv = fma(ax_, bx_, tv); tv = fma(ay_, by_, tv); tv = fma(az_, bz_, tv); tv = fma(aw_, bw_, tv); tt = 1.0; vv = 1.0; }
-            continue;
+            return;
 #endif
             const double ax = a.x, ay = a.y, az = a.z, aw = a.w, bx = b.x, by = b.y, bz = b.z, bw = b.w;
             tt = fma(ax, ax, tt); tt = fma(ay, ay, tt); tt = fma(az, az, tt); tt = fma(aw, aw, tt);
             vv = fma(bx, bx, vv); vv = fma(by, by, vv); vv = fma(bz, bz, vv); vv = fma(bw, bw, vv);
             tv = fma(ax, bx, tv); tv = fma(ay, by, tv); tv = fma(az, bz, tv); tv = fma(aw, bw, tv);
+        };
+#ifndef LAFF_EXACT_CH
+#define LAFF_EXACT_CH 4
+#endif
+        constexpr int CH = LAFF_EXACT_CH;                            // float4 columns of a lane per batch: 4 x 64 = 256 columns (8 loads in flight)
+        if (d % (RG * 4 * CH) == 0) {     // (CH = 8 -- a whole 512-d head at once -- needs 126 registers in the resolve kernel: 4 wavefronts per SIMD, slower)
+            // Heads of whole 256-column batches: the 8 row loads of a batch are ALL requested before the first product (arrays
+            // filled first, chains afterwards, in column order: the fma sequence -- and every bit of the result -- is that of the
+            // rolled loop below).  With `#pragma unroll 8` on that loop hipcc issued the loads in pairs with `s_waitcnt vmcnt(0)`
+            // between them -- eight dependent round trips per pair of scattered 2 KB rows (found in the ISA), which is what the
+            // resolve kernels were bound by.
+            for (int c0 = sl * 4; c0 < d; c0 += RG * 4 * CH) {
+                float4 a[CH], b[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    a[i] = load_t(h, c0 + i * (RG * 4));
+                    b[i] = *(const float4*)(vh + c0 + i * (RG * 4));
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) chain(a[i], b[i]);
+            }
+        } else {
+            for (int c = sl * 4; c < d; c += RG * 4) chain(load_t(h, c), *(const float4*)(vh + c));
         }
         tt = group_sum_f64(tt); vv = group_sum_f64(vv); tv = group_sum_f64(tv);
         if (tt_last) *tt_last = tt;                                  // (|t_h|^2 of the last head, for callers that need the norm too)

@@ -213,6 +213,35 @@ __device__ __forceinline__ void load_operand4(const void* __restrict__ op, long 
     }
 }
 
+// load_operand4 in two steps (raw words first, conversion later), for callers that request several columns before using any
+struct OperandRaw { uint2 hi, lo; float4 f; };
+template <int PREC>
+__device__ __forceinline__ void load_operand_raw(const void* __restrict__ op, long k, long plane, OperandRaw& r) {
+    if constexpr (PREC == LAFF_PREC_FP32) {
+        r.f = *(const float4*)((const float*)op + k);
+    } else {
+        r.hi = *(const uint2*)((const uint16_t*)op + k);
+        if constexpr (PREC == LAFF_PREC_FP16X3 || PREC == LAFF_PREC_BF16X3) r.lo = *(const uint2*)((const uint16_t*)op + plane + k);
+    }
+}
+template <int PREC>
+__device__ __forceinline__ void operand_from_raw(const OperandRaw& r, float (&x)[4]) {
+    if constexpr (PREC == LAFF_PREC_FP32) {
+        x[0] = r.f.x; x[1] = r.f.y; x[2] = r.f.z; x[3] = r.f.w;
+    } else {
+        auto cvt = [](uint16_t b) -> float {
+            if constexpr (PREC == LAFF_PREC_BF16 || PREC == LAFF_PREC_BF16X3) return __uint_as_float((unsigned)b << 16);
+            else { _Float16 f; __builtin_memcpy(&f, &b, 2); return (float)f; }
+        };
+        const uint2 o = r.hi;
+        x[0] = cvt((uint16_t)o.x); x[1] = cvt((uint16_t)(o.x >> 16)); x[2] = cvt((uint16_t)o.y); x[3] = cvt((uint16_t)(o.y >> 16));
+        if constexpr (PREC == LAFF_PREC_FP16X3 || PREC == LAFF_PREC_BF16X3) {
+            const uint2 l = r.lo;
+            x[0] += cvt((uint16_t)l.x); x[1] += cvt((uint16_t)(l.x >> 16)); x[2] += cvt((uint16_t)l.y); x[3] += cvt((uint16_t)(l.y >> 16));
+        }
+    }
+}
+
 // ONE pass over a row: q^2 = sum_k (x_k - e_k / n_h)^2 with x = operand / prescale and n_h = |e_h| + eps, expanded as
 // xx - 2 xe / n + ee / n^2 per head with the three sums in fp64 (the terms cancel to ~1e-8 of their size; fp64 leaves 1e-16), and --
 // WITH_GT -- the exact cosine against the ground-truth row v in the same loop.  tt / vv / tv use exactly exact_cos()'s lane map, fma
@@ -228,10 +257,8 @@ __device__ __forceinline__ float row_pass(const float* __restrict__ e, const voi
     for (int h = 0; h < H; ++h) {
         const float* eh = e + (long)h * d;
         double tt = 0.0, vv = 0.0, tv = 0.0, xx = 0.0, xe = 0.0;
-#pragma unroll 4
-        for (int c = sl * 4; c < d; c += RG * 4) {
-            const float4 a = *(const float4*)(eh + c);
-            float x[4];
+        // one column group of the lane: a = the embedding's float4, x = the operand's four values, b = the ground-truth row's float4
+        auto body = [&](int c, const float4& a, float (&x)[4], const float4& b) {
             if constexpr (EMIT && (PREC == LAFF_PREC_FP16 || PREC == LAFF_PREC_BF16)) {
                 const float s4[4] = {a.x * prescale, a.y * prescale, a.z * prescale, a.w * prescale};
                 uint16_t b4[4];
@@ -242,13 +269,10 @@ __device__ __forceinline__ float row_pass(const float* __restrict__ e, const voi
                 }
                 *(uint2*)((uint16_t*)const_cast<void*>(op) + row * K + (long)h * d + c) =
                     make_uint2((unsigned)b4[0] | ((unsigned)b4[1] << 16), (unsigned)b4[2] | ((unsigned)b4[3] << 16));
-            } else {
-                load_operand4<PREC>(op, row * K + (long)h * d + c, nrows * K, x);
             }
             const double ax = a.x, ay = a.y, az = a.z, aw = a.w;
             tt = fma(ax, ax, tt); tt = fma(ay, ay, tt); tt = fma(az, az, tt); tt = fma(aw, aw, tt);
             if constexpr (WITH_GT) {
-                const float4 b = *(const float4*)(v + (long)h * d + c);
                 const double bx = b.x, by = b.y, bz = b.z, bw = b.w;
                 vv = fma(bx, bx, vv); vv = fma(by, by, vv); vv = fma(bz, bz, vv); vv = fma(bw, bw, vv);
                 tv = fma(ax, bx, tv); tv = fma(ay, by, tv); tv = fma(az, bz, tv); tv = fma(aw, bw, tv);
@@ -256,6 +280,40 @@ __device__ __forceinline__ float row_pass(const float* __restrict__ e, const voi
             const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
             xx = fma(x0, x0, xx); xx = fma(x1, x1, xx); xx = fma(x2, x2, xx); xx = fma(x3, x3, xx);
             xe = fma(x0, ax, xe); xe = fma(x1, ay, xe); xe = fma(x2, az, xe); xe = fma(x3, aw, xe);
+        };
+        constexpr bool emits = EMIT && (PREC == LAFF_PREC_FP16 || PREC == LAFF_PREC_BF16);
+        constexpr int CH = LAFF_EXACT_CH;
+        if (d % (RG * 4 * CH) == 0) {
+            // whole batches of CH column groups: every load of a batch is requested before its first value is used (exact_cos.h has the
+            // reason: as one rolled / partially unrolled loop hipcc waited for each load, or pair of loads, before issuing the next);
+            // the chains run in column order afterwards -- the same fma sequence, the same bits
+            for (int c0 = sl * 4; c0 < d; c0 += RG * 4 * CH) {
+                float4 a[CH], b[CH];
+                OperandRaw o[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int c = c0 + i * (RG * 4);
+                    a[i] = *(const float4*)(eh + c);
+                    if constexpr (!emits) load_operand_raw<PREC>(op, row * K + (long)h * d + c, nrows * K, o[i]);
+                    if constexpr (WITH_GT) b[i] = *(const float4*)(v + (long)h * d + c);
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    float x[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (!emits) operand_from_raw<PREC>(o[i], x);
+                    body(c0 + i * (RG * 4), a[i], x, b[i]);
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int c = sl * 4; c < d; c += RG * 4) {
+                const float4 a = *(const float4*)(eh + c);
+                float x[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (!emits) load_operand4<PREC>(op, row * K + (long)h * d + c, nrows * K, x);
+                float4 b = make_float4(0, 0, 0, 0);
+                if constexpr (WITH_GT) b = *(const float4*)(v + (long)h * d + c);
+                body(c, a, x, b);
+            }
         }
         tt = group_sum_f64(tt);
         if constexpr (WITH_GT) { vv = group_sum_f64(vv); tv = group_sum_f64(tv); }
@@ -746,7 +804,10 @@ __device__ __forceinline__ void resolve_pairs(const float* __restrict__ Et, cons
                                               unsigned (*queue)[RESOLVE_QCAP][2]);
 
 // (six wavefronts per SIMD = the launch's 6 x CUs workgroups in one resident round: at most 80 VGPRs)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void rank_resolve_kernel(
+#ifndef LAFF_RESOLVE_WAVES
+#define LAFF_RESOLVE_WAVES 5      // 94 registers with 8 row loads in flight per 16-lane group (6 = 80 registers: spills)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LAFF_RESOLVE_WAVES))) void rank_resolve_kernel(
     const float* __restrict__ Et, const float* __restrict__ Ev, int H, int d, const double* __restrict__ s_gt64, int* __restrict__ count,
     float* __restrict__ S, long lds, unsigned* __restrict__ pairs, unsigned pair_cap, MetricsTail mt) {
     __shared__ __attribute__((aligned(16))) unsigned char pool[RESOLVE_POOL_BYTES];      // the pair queues, then the metrics tail's state
@@ -1010,7 +1071,7 @@ hipError_t launch_rank_resolve(const float* Et, const float* Ev, int Nt, int Nv,
     // one resident round: ~19 KiB of LDS and ~70 VGPRs per block admit 7 blocks per CU; 6 x CUs leaves a margin (a second, sparse
     // round of the 2,048-block grid doubled this launch's time)
     MetricsTail mt{metrics_n, base, ranks_out, out8, host8, ticket};
-    hipLaunchKernelGGL(rank_resolve_kernel, dim3((unsigned)(6 * g_num_cus)), dim3(256), 0, st, Et, Ev, H, d, s_gt64, count, S, (long)lds, pairs,
+    hipLaunchKernelGGL(rank_resolve_kernel, dim3((unsigned)(LAFF_RESOLVE_WAVES * g_num_cus)), dim3(256), 0, st, Et, Ev, H, d, s_gt64, count, S, (long)lds, pairs,
                        pair_cap, mt);
     return hipGetLastError();
 }
