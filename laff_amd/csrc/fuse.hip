@@ -642,12 +642,26 @@ __global__ __launch_bounds__(256) void frame_fuse_kernel(FrameGroup grp) {
     }
     if (mul) {
         // mean over ALL Fmax frames (padded zeros included, as in the reference): w <- w * sum_f x_f / Fmax
-        for (int f = wave; f < len; f += 4)
+        constexpr int FBM = NCH <= 2 ? 8 / NCH : 1;               // (frames requested together, added in frame order: see the main loop)
+        for (int f0 = wave; f0 < len; f0 += 4 * FBM) {
+            float4 xb[FBM][NCH];
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int col = j * 256 + lane * 4;
-                if (col < d) xs[j] = add4(xs[j], *(const float4*)(base + (long)f * d + col));
+            for (int i = 0; i < FBM; ++i) {
+                const int f = min(f0 + 4 * i, len - 1);
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const int col = j * 256 + lane * 4;
+                    xb[i][j] = *(const float4*)(base + (long)f * d + (col < d ? col : 0));
+                }
             }
+#pragma unroll
+            for (int i = 0; i < FBM; ++i) {
+                if (f0 + 4 * i >= len) break;
+#pragma unroll
+                for (int j = 0; j < NCH; ++j)
+                    if (j * 256 + lane * 4 < d) xs[j] = add4(xs[j], xb[i][j]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NCH; ++j) *(float4*)&sh_sum[wave][j * 256 + lane * 4] = xs[j];
         __syncthreads();
@@ -665,25 +679,42 @@ __global__ __launch_bounds__(256) void frame_fuse_kernel(FrameGroup grp) {
     float4 acc[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) acc[j] = make_float4(0, 0, 0, 0);
-    for (int f = wave; f < len; f += 4) {
-        float4 xv[NCH];
-        float p = 0.f;
+    // The wave's frames in batches of FB: every frame of a batch is requested before the first is used.  (One frame per trip, the
+    // online softmax made each load wait for the previous frame's reduction and exponentials: eight dependent HBM round trips per
+    // wave at 32 frames -- the launch was that chain, 0.10 ms at C3 for 0.4 GB.)  The frames are folded in the same order as before.
+    constexpr int FB = NCH <= 2 ? 8 / NCH : 1;
+    for (int f0 = wave; f0 < len; f0 += 4 * FB) {
+        float4 xb[FB][NCH];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int col = j * 256 + lane * 4;
-            xv[j] = col < d ? *(const float4*)(base + (long)f * d + col) : make_float4(0, 0, 0, 0);
-            p += dot4(xv[j], wv[j]);
-        }
-        const float lg = wave_sum(p) + bias;
-        const float mn = fmaxf(m, lg);
-        const float r = expf(m - mn), e = expf(lg - mn);
-        s = s * r + e;
+        for (int i = 0; i < FB; ++i) {
+            const int f = min(f0 + 4 * i, len - 1);                 // (frames beyond the clip: a valid address, never folded in)
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            acc[j] = fma4(xv[j], e, scl4(acc[j], r));
-            xs[j] = add4(xs[j], xv[j]);
+            for (int j = 0; j < NCH; ++j) {
+                const int col = j * 256 + lane * 4;
+                xb[i][j] = *(const float4*)(base + (long)f * d + (col < d ? col : 0));
+            }
         }
-        m = mn;
+#pragma unroll
+        for (int i = 0; i < FB; ++i) {
+            if (f0 + 4 * i >= len) break;                           // wave-uniform
+            float4 xv[NCH];
+            float p = 0.f;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                xv[j] = (j * 256 + lane * 4 < d) ? xb[i][j] : make_float4(0, 0, 0, 0);
+                p += dot4(xv[j], wv[j]);
+            }
+            const float lg = wave_sum(p) + bias;
+            const float mn = fmaxf(m, lg);
+            const float r = expf(m - mn), e = expf(lg - mn);
+            s = s * r + e;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                acc[j] = fma4(xv[j], e, scl4(acc[j], r));
+                xs[j] = add4(xs[j], xv[j]);
+            }
+            m = mn;
+        }
     }
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
