@@ -412,14 +412,39 @@ __global__ __launch_bounds__(256) LAFF_FUSE_WAVES_ATTR void fuse_reg_kernel(Fuse
 
     float4 x[L][NCH];
     float4 wv[NCH];
-    // every dense plane's raw values first: L * NCH loads in flight together (see load_plane_raw)
+    // every dense plane's raw values first: L * NCH loads in flight together (see load_plane_raw).  The planes' kernel arguments are
+    // read up front (as part of each conditional load they were one scalar load + wait per plane chunk, between the vector loads), and
+    // whole heads (d = 256 NCH: every lane has all its columns) take loads without a per-lane test (no EXEC-masked block per load).
+    const float* psrc[L];
+    long pld[L];
+    bool pdense[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l)
+    for (int l = 0; l < L; ++l) {
+        psrc[l] = a.src[l] + (a.tile[l] ? 0 : h * a.head_stride);
+        pld[l] = a.ld[l];
+        pdense[l] = !a.g_wt[l];
+    }
+    typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+    if (d == 256 * NCH) {
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int col = j * 256 + lane * 4;
-            x[l][j] = (!a.g_wt[l] && col < d) ? load_plane_raw(a, l, n, h, col) : make_float4(0, 0, 0, 0);
-        }
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                x[l][j] = make_float4(0, 0, 0, 0);
+                if (pdense[l]) {                                             // wave-uniform
+                    const nt_f32x4 nv = __builtin_nontemporal_load((const nt_f32x4*)(psrc[l] + n * pld[l] + j * 256 + lane * 4));
+                    x[l][j] = make_float4(nv.x, nv.y, nv.z, nv.w);
+                }
+            }
+    } else {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int col = j * 256 + lane * 4;
+                x[l][j] = (pdense[l] && col < d) ? load_plane_raw(a, l, n, h, col) : make_float4(0, 0, 0, 0);
+            }
+    }
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int col = j * 256 + lane * 4;
