@@ -129,7 +129,10 @@ __device__ __forceinline__ void pin_v(T& x) { asm volatile("" : "+v"(x)); }
 // address = voff0 + ROWMUL * ldy4, made right in front of the store (one address register instead of one per accumulator)
 template <int ROWMUL>
 __device__ __forceinline__ void store_row(unsigned& tmp, float data, unsigned voff0, unsigned ldy4, u32x4 rsrc, unsigned soff) {
-    asm volatile("v_mad_u32_u24 %0, %3, %4, %2\n\tbuffer_store_dword %1, %0, %5, %6 offen nt"
+#ifndef LAFF_FCS_STFLAVOR
+#define LAFF_FCS_STFLAVOR "nt"
+#endif
+    asm volatile("v_mad_u32_u24 %0, %3, %4, %2\n\tbuffer_store_dword %1, %0, %5, %6 offen " LAFF_FCS_STFLAVOR
                  : "=&v"(tmp) : "v"(data), "v"(voff0), "s"(ldy4), "n"(ROWMUL), "s"(rsrc), "s"(soff) : "memory");
 }
 

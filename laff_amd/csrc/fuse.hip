@@ -432,7 +432,11 @@ __global__ __launch_bounds__(256) LAFF_FUSE_WAVES_ATTR void fuse_reg_kernel(Fuse
             for (int j = 0; j < NCH; ++j) {
                 x[l][j] = make_float4(0, 0, 0, 0);
                 if (pdense[l]) {                                             // wave-uniform
+#ifdef LAFF_FUSE_PLANE_PLAIN
+                    const nt_f32x4 nv = *(const nt_f32x4*)(psrc[l] + n * pld[l] + j * 256 + lane * 4);
+#else
                     const nt_f32x4 nv = __builtin_nontemporal_load((const nt_f32x4*)(psrc[l] + n * pld[l] + j * 256 + lane * 4));
+#endif
                     x[l][j] = make_float4(nv.x, nv.y, nv.z, nv.w);
                 }
             }
