@@ -12,7 +12,8 @@ dev = torch.device('cuda')
 g = torch.Generator(device='cpu').manual_seed(1)
 probs = []
 PITCH = int(os.environ.get('FCS_PITCH', '512'))
-for N in (40000,) * 4 + (10000,) * 4:
+NT_, NV_ = (int(v) for v in os.environ.get('FCS_SHAPE', '40000,10000').split(','))      # rows of the text / video features (4 each)
+for N in (NT_,) * 4 + (NV_,) * 4:
     x = torch.randn((N, 512), generator=g).to(dev)
     if PITCH != 512:
         buf = torch.zeros((N, PITCH), device=dev)
@@ -32,9 +33,10 @@ torch.cuda.synchronize()
 os.environ.pop('LAFF_GEMM_TRACE_PTR')
 a = tr.cpu().numpy().reshape(nwg, 80).astype(np.int64)
 seg = a[:, :64].reshape(nwg, 8, 8)
-t0 = a[:, 0].min()
+liv = a[:, 0] > 0
+t0 = a[liv, 0].min()
 ends = seg[:, :, 6].max(axis=1)
-print('kernel span (cycles): %d   starts spread %d   end spread %d' % (ends.max() - t0, a[:, 0].max() - t0, ends.max() - ends.min()))
+print('workgroups that stamped: %d; kernel span (cycles): %d   starts spread %d (p50 %d)   end spread %d' % (liv.sum(), ends[liv].max() - t0, a[liv, 0].max() - t0, np.median(a[liv, 0]) - t0, ends[liv].max() - ends[liv].min()))
 names = ['strip -> registers (raw) + barrier', 'W prologue issue', 'converted', 'prologue landed + barrier', 'block loop', 'drain + segment end']
 tot = np.zeros(6)
 nseg = nblk = 0
@@ -52,3 +54,10 @@ for s in range(8):
     nblk += n.sum()
 print('totals per workgroup (cycles): ' + '  '.join('%s %.0f' % (nm, v / nwg) for nm, v in zip(names, tot)) + '  | sum %.0f' % (tot.sum() / nwg))
 print('segments per workgroup %.2f, blocks per workgroup %.1f, loop cycles per block %.0f (MFMA issue alone: 3072)' % (nseg / nwg, nblk / nwg, tot[4] / nblk))
+# per-workgroup busy time (first stamp of its first segment to last stamp of its last one: one clock domain per workgroup)
+first = seg[:, 0, 0].astype(np.float64)
+last = seg[:, :, 6].max(axis=1).astype(np.float64)
+busy = (last - first)[liv]
+xcd = np.arange(nwg)[liv] % 8
+print('busy cycles per workgroup: mean %.0f  p50 %.0f  p95 %.0f  max %.0f  min %.0f' % (busy.mean(), np.median(busy), np.percentile(busy, 95), busy.max(), busy.min()))
+print('by XCD (mean / max): ' + '  '.join('%d: %.0f / %.0f' % (x, busy[xcd == x].mean(), busy[xcd == x].max()) for x in range(8)))
