@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'liblaff_hip.so')
 SOURCES = ['gemm_nt.hip', 'sim_strip.hip', 'fc_strip.hip', 'fuse.hip', 'rank.hip', 'loss.hip', 'comm.hip', 'api.hip']
-HEADERS = [os.path.join(CSRC, 'kernels.h'), os.path.join(CSRC, 'exact_cos.h'), os.path.join(CSRC, 'strip_util.h'), os.path.join(os.path.dirname(HERE), 'include', 'laff_hip.h')]
+HEADERS = [os.path.join(CSRC, 'kernels.h'), os.path.join(CSRC, 'exact_cos.h'), os.path.join(CSRC, 'strip_util.h'), os.path.join(CSRC, 'wave_reduce.h'), os.path.join(os.path.dirname(HERE), 'include', 'laff_hip.h')]
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++20', '-fPIC', '--offload-arch=' + ARCH, '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 

@@ -5,19 +5,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "wave_reduce.h"
+
 namespace laff {
 
 constexpr int RG = 16;                         // lanes per row / pair
-__device__ __forceinline__ double group_sum_f64(double v) {
-#pragma unroll
-    for (int o = RG / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float group_sum_f32(float v) {
-#pragma unroll
-    for (int o = RG / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+// All-lanes sums of a 16-lane group (= one DPP row), xor butterfly 8, 4, 2, 1 as row rotations (wave_reduce.h: bit for bit what the
+// `__shfl_xor` butterfly gave, without its ds_bpermute_b32 -- two per step for a double --, index arithmetic and LDS wait per step).
+// All lanes of the row must be active (callers keep idle groups in step for that).
+static_assert(RG == 16, "the group reductions below are DPP row operations");
+__device__ __forceinline__ double group_sum_f64(double v) { return wave_allreduce<8>(v, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ float group_sum_f32(float v) { return wave_allreduce<8>(v, [](float a, float b) { return a + b; }); }
 
 constexpr double COS_EPS = 1e-13 + 1e-14;      // loss.cosine_sim -> l2norm(eps=1e-13): X / (norm + eps + 1e-14)  (loss.py:8-13,30-34)
 

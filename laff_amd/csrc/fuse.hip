@@ -16,19 +16,14 @@
 
 #include "kernels.h"
 #include "exact_cos.h"
+#include "wave_reduce.h"
 
 namespace laff {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
+// all-lanes reductions of a wavefront: wave_reduce.h (the xor butterfly's order and bits, on lane swaps + DPP row rotations; as
+// `__shfl_xor` loops fuse_reg_kernel<4, 2> held 101 ds_bpermute_b32 with their index arithmetic and LDS waits)
+__device__ __forceinline__ float wave_sum(float v) { return wave_allsum(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_allmax(v); }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 scl4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }

@@ -13,14 +13,11 @@
 // dLoss/dScores, and the backward of the row normalisation.  Batches are small (B ~ 128..1024): everything here is
 // latency-bound and sized as one wave per row / one workgroup per head.
 #include "kernels.h"
+#include "wave_reduce.h"
 
 namespace laff {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_allsum(v); }      // (wave_reduce.h: the butterfly's bits, no LDS crossbar)
 
 // grid (B, H, 2): z = 0 captions (s), z = 1 videos (im); one wave per row.
 // XH[z][h][b][dp] = x / (|x| + eps + 1e-14),  XHT[z][h][k][Bp] its transpose,  nrm[z][h][b] = |x|,  npr = |x| + eps + 1e-14

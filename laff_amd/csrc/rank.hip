@@ -9,6 +9,7 @@
 
 #include "kernels.h"
 #include "exact_cos.h"
+#include "wave_reduce.h"
 
 // Cross-workgroup hand-off of the metrics tails (rank_metrics_kernel, rank_resolve_kernel).  Default: no fences -- the partials travel
 // as device-scope stores / atomics, are complete once `s_waitcnt vmcnt(0)` returns, and the ticket is a relaxed device-scope atomic behind
@@ -59,8 +60,7 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const float* __restrict
     } else {
         for (int c = threadIdx.x; c < Nv; c += 256) cnt += (row[c] > sg && c != gt);
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+    cnt = wave_allsum(cnt);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -161,8 +161,7 @@ __global__ __launch_bounds__(256) void row_dot_gt_kernel(const uint16_t* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc = fmaf(cvt(pa[e]), cvt(pb[e]), acc);
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    acc = wave_allsum(acc);
     if (lane == 0) s_gt[t] = acc * scale;
 }
 
@@ -547,8 +546,7 @@ __device__ void metrics_single_block(const int* r, int n, int base, int* ranks_o
     }
     // (32 consecutive threads hold one 256-rank block of mid[]: its total is what hi[1 + tid / 32] lacks)
     unsigned blk = msum;
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) blk += __shfl_xor(blk, o);
+    blk = wave_allreduce<16>(blk, [](unsigned a, unsigned b) { return a + b; });      // (32 consecutive lanes each)
     unsigned c5 = 0, c10 = 0;
     if (tid == 1) own_lo = 0;                                     // (lo[1] is n1, added below)
     if (tid >= 2) {
@@ -557,13 +555,10 @@ __device__ void metrics_single_block(const int* r, int n, int base, int* ranks_o
         if (own_lo) isum += (double)own_lo / (double)tid;
     }
     unsigned nmid = msum;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        n1 += __shfl_xor(n1, o); nbig += __shfl_xor(nbig, o); nmid += __shfl_xor(nmid, o); sum += __shfl_xor(sum, o);
-        c5 += __shfl_xor(c5, o); c10 += __shfl_xor(c10, o);
-        isum += __shfl_xor(isum, o);
-        mx = max(mx, __shfl_xor(mx, o)); mn = min(mn, __shfl_xor(mn, o));
-    }
+    n1 = wave_allsum(n1); nbig = wave_allsum(nbig); nmid = wave_allsum(nmid); sum = wave_allsum(sum);
+    c5 = wave_allsum(c5); c10 = wave_allsum(c10);
+    isum = wave_allsum(isum);
+    mx = wave_allmax(mx); mn = wave_allmin(mn);
     if (lane == 0) {
         L.shl[wave][0] = n1 | ((unsigned long long)nbig << 32); L.shl[wave][1] = c5 | ((unsigned long long)c10 << 32);
         L.shl[wave][2] = nmid; L.shl[wave][3] = sum;
@@ -662,8 +657,7 @@ __device__ void metrics_single_block(const int* r, int n, int base, int* ranks_o
             each([&](int, int v) {
                 if (v < med_lo) below = max(below, v);
             });
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) below = max(below, __shfl_xor(below, o));
+            below = wave_allmax(below);
             __syncthreads();
             if (lane == 0) L.shm[wave][0] = below;
             __syncthreads();
@@ -1137,12 +1131,9 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
         atomicAdd(&hist[(256u + min(u >> 8, 255u)) * 9 + rep8], 1u);
     }
     auto block_sums = [&]() {                                     // -> thread 0 holds the block's totals
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            c1 += __shfl_xor(c1, o); c5 += __shfl_xor(c5, o); c10 += __shfl_xor(c10, o); sum += __shfl_xor(sum, o);
-            isum += __shfl_xor(isum, o);
-            mx = max(mx, __shfl_xor(mx, o)); mn = min(mn, __shfl_xor(mn, o));
-        }
+        c1 = wave_allsum(c1); c5 = wave_allsum(c5); c10 = wave_allsum(c10); sum = wave_allsum(sum);
+        isum = wave_allsum(isum);
+        mx = wave_allmax(mx); mn = wave_allmin(mn);
         if (lane == 0) {
             shl[wave][0] = c1; shl[wave][1] = c5; shl[wave][2] = c10; shl[wave][3] = sum;
             shd[wave] = isum;
@@ -1291,8 +1282,7 @@ __global__ __launch_bounds__(1024) void rank_metrics_kernel(const int* __restric
             each([&](int v) {
                 if (v < med_lo) below = max(below, v);
             });
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) below = max(below, __shfl_xor(below, o));
+            below = wave_allmax(below);
             __syncthreads();
             if (lane == 0) shm[wave][0] = below;
             __syncthreads();
