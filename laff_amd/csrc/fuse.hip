@@ -394,8 +394,13 @@ __global__ __launch_bounds__(256) LAFF_FUSE_WAVES_ATTR void fuse_reg_kernel(Fuse
     } else {
         const long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
         if (it >= (long)a.N * a.H) { rank_side_idle(a); return; }
-        n = it / a.H;
-        h = (int)(it - n * a.H);
+        if (a.H == 1) {                                          // (one head: no 64-bit division per wavefront)
+            n = it;
+            h = 0;
+        } else {
+            n = it / a.H;
+            h = (int)(it - n * a.H);
+        }
     }
     // one item per wavefront: (n, h) are wave-uniform, but derived from threadIdx they look divergent to the compiler -- pinned to
     // scalars, every row base (src + n * ld, E + item * d, ...) becomes SALU work and the loads take the scalar-base + 32-bit lane
