@@ -135,6 +135,63 @@ def test_fc_strip_kernels_keep_out_of_the_accumulator_registers(tmp_path):
         assert int(re.search(r'\.sgpr_spill_count: (\d+)', meta).group(1)) == 0
 
 
+def test_compiler_scheduled_kernels_keep_their_loads_in_flight(tmp_path):
+    """Round 6 found hipcc waiting for every load by itself in the C++ kernels (a `global_load` + `s_waitcnt vmcnt(0)` per plane chunk in
+    the fusion kernel, per pair of row pieces in the exact re-score) and compiling `__shfl_xor` reductions to the LDS crossbar.  The
+    sources are written so that it cannot (raw loads into arrays first; lane swaps + DPP rotations): this holds the ISA to it.
+      * fuse_reg_kernel<4, 2>: its eight whole-head plane loads (scalar base, `nt`) come with no vector-memory wait between them;
+      * rank_resolve_kernel: somewhere eight 16-byte row loads are issued back to back, no spill;
+      * their reductions are DPP row rotations (row_ror), not ds_bpermute_b32."""
+    import re
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from laff_amd import build
+
+    def asm_of(name):
+        out = str(tmp_path / (name + '.s'))
+        flags = [f for f in build.FLAGS if f != '-fPIC']
+        r = subprocess.run([build.hipcc()] + flags + ['--cuda-device-only', '-S', os.path.join(build.CSRC, name + '.hip'), '-o', out],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return open(out).read()
+
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        fuse, rank = ex.map(asm_of, ['fuse', 'rank'])
+
+    def body(text, mangled_prefix):
+        m = re.search(r'^(%s\S*):' % re.escape(mangled_prefix), text, re.M)
+        assert m, mangled_prefix
+        rest = text[m.end():]
+        return [ln.split(';')[0].strip() for ln in rest[:rest.index('.amdhsa_kernel')].split('\n')]
+
+    f42 = [i for i in body(fuse, '_ZN4laff15fuse_reg_kernelILi4ELi2E') if i and not i.startswith('.')]
+    # the longest run of nt plane loads with a scalar base that no `s_waitcnt vmcnt` interrupts
+    best = run = 0
+    for ins in f42:
+        if re.match(r'global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[\d+:\d+\].* nt', ins):
+            run += 1
+            best = max(best, run)
+        elif ins.startswith('s_waitcnt') and 'vmcnt' in ins:
+            run = min(run, int(re.search(r'vmcnt\((\d+)\)', ins).group(1)))      # vmcnt(n): the n youngest requests stay in flight
+    assert best >= 8, 'fuse_reg_kernel<4, 2>: at most %d plane loads in flight' % best
+    assert sum(i.startswith('ds_bpermute') for i in f42) <= 1              # (the several-heads ticket broadcast of the rank side)
+    assert sum('row_ror' in i for i in f42) >= 16                          # the reductions' DPP rotations
+    res = [i for i in body(rank, '_ZN4laff19rank_resolve_kernel') if i and not i.startswith('.')]
+    best = run = 0
+    for ins in res:
+        if ins.startswith('global_load_dwordx4'):
+            run += 1
+            best = max(best, run)
+        elif ins.startswith('s_waitcnt') and 'vmcnt' in ins:
+            run = min(run, int(re.search(r'vmcnt\((\d+)\)', ins).group(1)))
+    assert best >= 8, 'rank_resolve_kernel: at most %d row loads issued together' % best
+    assert sum(i.startswith('v_mov_b32_dpp') and 'row_ror' in i for i in res) >= 16     # the fp64 group sums travel by DPP
+    meta = rank[rank.index('.name:           _ZN4laff19rank_resolve_kernel'):]
+    assert int(re.search(r'\.vgpr_spill_count: (\d+)', meta).group(1)) == 0
+    meta = fuse[fuse.index('.name:           _ZN4laff15fuse_reg_kernelILi4ELi2E'):]
+    assert int(re.search(r'\.vgpr_spill_count: (\d+)', meta).group(1)) == 0
+
+
 def _build_c_host(out_dir):
     """tests/c_host/laff_host.c: plain C11 against include/laff_hip.h, built with gcc (no hipcc, no torch) and linked to the library."""
     import subprocess
